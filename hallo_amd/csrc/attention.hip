@@ -1,0 +1,407 @@
+// Flash-style attention for gfx950 with two key/value segments.
+//
+// Replaces diffusers AttnProcessor2_0 (F.scaled_dot_product_attention) as called from
+//   hallo/models/mutual_self_attention.py:253-284 (spatial self-attention whose K/V is the
+//     concatenation [self ; ReferenceNet bank], CFG uncond rows attending to self only),
+//   hallo/models/attention.py:828-831 (audio block self-attention),
+//   hallo/models/mutual_self_attention.py:296-303 (4 face tokens) and
+//   hallo/models/attention.py:846-884 (3 x 32 audio tokens).
+//
+// Work decomposition: one 256-thread workgroup = 128 query rows of one (batch, head);
+// each of the 4 waves owns 32 query rows.  K/V tiles (KVB rows) are staged global -> VGPR -> LDS
+// with the next tile in flight under the current tile's MFMAs.
+//
+// Both contractions use the "swapped" MFMA form so that every lane owns one query row:
+//   S^T[kv, q] = K[kv, :] . Q[q, :]^T      (A = K tile from LDS, B = Q fragment in registers)
+//   O^T[d,  q] = V^T[d, :] . P^T[:, q]     (A = V^T tile from LDS, B = P in registers)
+// so the online-softmax statistics (row max / row sum) and the O rescale are lane-local, with a
+// single cross-lane exchange (lane ^ 32) for the row max.  P never leaves registers: the k-slot
+// order of the second MFMA is chosen to match the accumulator layout of the first
+// (kv = 16*h2 + (j&3) + 8*(j>>2) + 4*hi for slot j of lane half hi), and the V^T fragment is read
+// from LDS with the same permutation (two 8-byte reads per fragment).
+#include "common.h"
+#include "../../include/hallo_amd.h"
+
+namespace hallo {
+
+struct AttnArgs {
+  const void* q; const void* k1; const void* v1; const void* k2; const void* v2; void* o;
+  int batch, heads, Lq, Lkv1, Lkv2;
+  long q_bs, q_rs, k1_bs, k1_rs, v1_bs, v1_rs, k2_bs, k2_rs, v2_bs, v2_rs, o_bs, o_rs;
+  int kv2_div, kv2_first;
+  float scale_log2e;
+  int nqb;  // query blocks per (batch, head)
+};
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  constexpr int KVB = (HD > 80) ? 32 : 64;       // kv rows per tile
+  constexpr int HDP = ((HD + 15) / 16) * 16;     // head dim padded to the MFMA K step
+  constexpr int NKS = HDP / 16;                  // QK^T k-steps
+  constexpr int NDB = (HD + 31) / 32;            // 32-wide d blocks of O^T
+  constexpr int NT = KVB / 32;                   // S^T row tiles per kv tile
+  constexpr int NCH = HD / 8;                    // 16-byte chunks per K/V row
+  constexpr int K_LD = HDP + 8;                  // LDS row pitch of K (elements)
+  constexpr int VT_LD = KVB + 4;                 // LDS row pitch of V^T (elements)
+  constexpr int KU = (KVB * NCH + 255) / 256;    // K loader units per thread
+  constexpr int VU = ((KVB / 2) * NCH + 255) / 256;  // V loader units (kv pairs) per thread
+
+  __shared__ __attribute__((aligned(16))) T sK[KVB * K_LD];
+  __shared__ __attribute__((aligned(16))) T sVT[NDB * 32 * VT_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  // block id -> (batch, head, q block), XCD-contiguous so a (batch, head)'s K/V stays in one L2
+  const int nwg = p.batch * p.heads * p.nqb;
+  int bid = xcd_remap(blockIdx.x, nwg);
+  const int qb = bid % p.nqb; bid /= p.nqb;
+  const int h = bid % p.heads;
+  const int b = bid / p.heads;
+
+  const T* __restrict__ Qg = reinterpret_cast<const T*>(p.q) + (long)b * p.q_bs + h * HD;
+  const T* __restrict__ K1 = reinterpret_cast<const T*>(p.k1) + (long)b * p.k1_bs + h * HD;
+  const T* __restrict__ V1 = reinterpret_cast<const T*>(p.v1) + (long)b * p.v1_bs + h * HD;
+  const bool use2 = p.k2 != nullptr && p.Lkv2 > 0 && b >= p.kv2_first;
+  const int b2 = use2 ? b / p.kv2_div : 0;
+  const T* __restrict__ K2 = use2 ? reinterpret_cast<const T*>(p.k2) + (long)b2 * p.k2_bs + h * HD : K1;
+  const T* __restrict__ V2 = use2 ? reinterpret_cast<const T*>(p.v2) + (long)b2 * p.v2_bs + h * HD : V1;
+  T* __restrict__ Og = reinterpret_cast<T*>(p.o) + (long)b * p.o_bs + h * HD;
+
+  // zero the K pad columns (HD..HDP-1) once; the loaders never touch them
+  if (HDP > HD) {
+    for (int r = tid; r < KVB; r += 256) st8<T>(&sK[r * K_LD + NCH * 8], zero8<T>());
+  }
+
+  // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + l31][ks*16 + hi*8 .. +8] ----
+  const int q0 = qb * 128 + wave * 32;
+  const int qrow = min(q0 + l31, p.Lq - 1);
+  V8 qf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int d = ks * 16 + hi * 8;
+    qf[ks] = (d < HD) ? ld8<T>(Qg + (long)qrow * p.q_rs + d) : zero8<T>();
+  }
+
+  const int nt1 = (p.Lkv1 + KVB - 1) / KVB;
+  const int nt2 = use2 ? (p.Lkv2 + KVB - 1) / KVB : 0;
+  const int nt = nt1 + nt2;
+
+  V8 rk[KU];
+  V8 rv[VU][2];
+  auto load_tile = [&](int it) {
+    const bool s2 = it >= nt1;
+    const T* Kp = s2 ? K2 : K1;
+    const T* Vp = s2 ? V2 : V1;
+    const long krs = s2 ? p.k2_rs : p.k1_rs, vrs = s2 ? p.v2_rs : p.v1_rs;
+    const int L = s2 ? p.Lkv2 : p.Lkv1;
+    const int kv0 = (s2 ? it - nt1 : it) * KVB;
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+      const int u = tid + 256 * i;
+      if (u < KVB * NCH) {
+        const int row = u / NCH, ch = u - row * NCH;
+        const int kv = min(kv0 + row, L - 1);
+        rk[i] = ld8<T>(Kp + (long)kv * krs + ch * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VU; ++i) {
+      const int u = tid + 256 * i;
+      if (u < (KVB / 2) * NCH) {
+        const int pr = u % (KVB / 2), ch = u / (KVB / 2);
+        const int kva = min(kv0 + 2 * pr, L - 1), kvb = min(kv0 + 2 * pr + 1, L - 1);
+        rv[i][0] = ld8<T>(Vp + (long)kva * vrs + ch * 8);
+        rv[i][1] = ld8<T>(Vp + (long)kvb * vrs + ch * 8);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+      const int u = tid + 256 * i;
+      if (u < KVB * NCH) {
+        const int row = u / NCH, ch = u - row * NCH;
+        st8<T>(&sK[row * K_LD + ch * 8], rk[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VU; ++i) {
+      const int u = tid + 256 * i;
+      if (u < (KVB / 2) * NCH) {
+        const int pr = u % (KVB / 2), ch = u / (KVB / 2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // V^T[d = ch*8 + j][kv = 2*pr, 2*pr+1] as one 4-byte store
+          typedef __attribute__((ext_vector_type(2))) T V2t;
+          V2t w;
+          w[0] = rv[i][0][j];
+          w[1] = rv[i][1][j];
+          *reinterpret_cast<V2t*>(&sVT[(ch * 8 + j) * VT_LD + 2 * pr]) = w;
+        }
+      }
+    }
+  };
+
+  f32x16 oacc[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.0f;
+  float m_run = -1e30f, l_run = 0.0f;
+
+  if (nt > 0) {
+    load_tile(0);
+    store_tile();
+  }
+  __syncthreads();
+
+  for (int it = 0; it < nt; ++it) {
+    if (it + 1 < nt) load_tile(it + 1);
+
+    // ---- S^T = K . Q^T ----
+    f32x16 s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        V8 kf = ld8<T>(&sK[(t * 32 + l31) * K_LD + ks * 16 + hi * 8]);
+        s[t] = Vec<T>::mfma32(kf, qf[ks], s[t]);
+      }
+    }
+
+    // ---- scale, mask, online softmax (lane-local row; partner lane^32 holds the other kv half) ----
+    const bool s2 = it >= nt1;
+    const int L = s2 ? p.Lkv2 : p.Lkv1;
+    const int kv0 = (s2 ? it - nt1 : it) * KVB;
+    const bool partial = kv0 + KVB > L;
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = s[t][r] * p.scale_log2e;
+        if (partial) {
+          const int kv = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          v = (kv < L) ? v : -1e30f;
+        }
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.0f;
+    V8 pf[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(s[t][r] - m_new);
+        psum += pv;
+        pf[t][r >> 3][r & 7] = from_f32<T>(pv);
+      }
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int kvl = t * 32 + h2 * 16 + hi * 4;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+          const T* vp = &sVT[(db * 32 + l31) * VT_LD + kvl];
+          V4 lo = *reinterpret_cast<const V4*>(vp);
+          V4 hi4 = *reinterpret_cast<const V4*>(vp + 8);
+          V8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi4[j]; }
+          oacc[db] = Vec<T>::mfma32(vf, pf[t][h2], oacc[db]);
+        }
+      }
+    }
+
+    __syncthreads();
+    if (it + 1 < nt) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+  // ---- normalise and store: lane owns row q0+l31, d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  if (q0 + l31 < p.Lq) {
+    T* orow = Og + (long)(q0 + l31) * p.o_rs;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + 8 * g + 4 * hi;
+        if (d0 < HD) {
+          V4 w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = from_f32<T>(oacc[db][g * 4 + j] * inv);
+          *reinterpret_cast<V4*>(orow + d0) = w;
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+static int launch_attn(const AttnArgs& a, int hd, hipStream_t st) {
+  dim3 grid(a.batch * a.heads * a.nqb), block(256);
+  switch (hd) {
+    case 40: hipLaunchKernelGGL((attn_kernel<T, 40>), grid, block, 0, st, a); break;
+    case 80: hipLaunchKernelGGL((attn_kernel<T, 80>), grid, block, 0, st, a); break;
+    case 160: hipLaunchKernelGGL((attn_kernel<T, 160>), grid, block, 0, st, a); break;
+    default: return -22;
+  }
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------
+// Temporal (per-pixel, over frames) attention.  One workgroup = one pixel of one batch entry and
+// a group of HPB heads; the F' x 3 x (HPB*hd) slab [q|k|v] of that pixel is staged in LDS with
+// coalesced row-segment loads.  Scores (F' x F', F' <= 32) and the PV product run on the VALU:
+// the op is HBM/layout bound (0.1 % of the step's FLOPs); the point of the kernel is
+// to remove the four "(b f) d c <-> (b d) f c" transposes around it.
+// -------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                            int F, int HW, int C, int hd, int hpb,
+                                                            float scale_log2e) {
+  using V8 = typename Vec<T>::v8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int Wd = hpb * hd;                    // channels handled by this block
+  T* sQKV = reinterpret_cast<T*>(smem_raw);   // [F][3][Wd]
+  float* sP = reinterpret_cast<float*>(smem_raw + (size_t)F * 3 * Wd * sizeof(T));  // [hpb][F][F+1]
+
+  const int tid = threadIdx.x;
+  const int pix = blockIdx.x % HW, b = blockIdx.x / HW;
+  const int cbase = blockIdx.y * Wd;          // first channel of this head group
+  const long C3 = 3L * C;
+  const int vpp = Wd / 8;                     // 16-byte vectors per part
+  const int W3 = 3 * Wd;
+
+  for (int u = tid; u < F * 3 * vpp; u += 256) {
+    const int f = u / (3 * vpp), rem = u - f * 3 * vpp;
+    const int part = rem / vpp, v = rem - part * vpp;
+    const long row = ((long)(b * F + f) * HW + pix);
+    st8<T>(&sQKV[f * W3 + part * Wd + v * 8], ld8<T>(qkv + row * C3 + (long)part * C + cbase + v * 8));
+  }
+  __syncthreads();
+
+  const int FP = F + 1;
+  const int nsc = hpb * F * F;
+  for (int u = tid; u < nsc; u += 256) {
+    const int hh = u / (F * F), rem = u - hh * F * F;
+    const int i = rem / F, j = rem - i * F;
+    const T* qp = &sQKV[i * W3 + hh * hd];
+    const T* kp = &sQKV[j * W3 + Wd + hh * hd];
+    float acc = 0.0f;
+    for (int d = 0; d < hd; d += 8) {
+      V8 a = ld8<T>(qp + d), k = ld8<T>(kp + d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += to_f32(a[e]) * to_f32(k[e]);
+    }
+    sP[(hh * F + i) * FP + j] = acc * scale_log2e;
+  }
+  __syncthreads();
+  for (int u = tid; u < hpb * F; u += 256) {
+    float* row = &sP[u * FP];
+    float mx = -1e30f;
+    for (int j = 0; j < F; ++j) mx = fmaxf(mx, row[j]);
+    float sum = 0.0f;
+    for (int j = 0; j < F; ++j) { const float e = exp2f(row[j] - mx); row[j] = e; sum += e; }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < F; ++j) row[j] *= inv;
+  }
+  __syncthreads();
+  for (int u = tid; u < F * vpp; u += 256) {
+    const int i = u / vpp, v = u - i * vpp;
+    const int c0 = v * 8, hh = c0 / hd;
+    const float* prow = &sP[(hh * F + i) * FP];
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+    for (int j = 0; j < F; ++j) {
+      const float pj = prow[j];
+      V8 vv = ld8<T>(&sQKV[j * W3 + 2 * Wd + c0]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += pj * to_f32(vv[e]);
+    }
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(acc[e]);
+    const long row = ((long)(b * F + i) * HW + pix);
+    st8<T>(out + row * C + cbase + c0, o);
+  }
+}
+
+}  // namespace hallo
+
+using namespace hallo;
+
+extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
+  if (!d || !d->q || !d->k1 || !d->v1 || !d->o) return -22;
+  if (d->batch <= 0 || d->heads <= 0 || d->Lq <= 0 || d->Lkv1 <= 0) return -22;
+  if (d->head_dim != 40 && d->head_dim != 80 && d->head_dim != 160) return -22;
+  if ((d->q_rs & 7) || (d->k1_rs & 7) || (d->v1_rs & 7) || (d->o_rs & 3)) return -22;
+  if (d->k2 && (!d->v2 || (d->k2_rs & 7) || (d->v2_rs & 7) || d->kv2_batch_div < 1)) return -22;
+  AttnArgs a;
+  a.q = d->q; a.k1 = d->k1; a.v1 = d->v1; a.k2 = d->k2; a.v2 = d->v2; a.o = d->o;
+  a.batch = d->batch; a.heads = d->heads; a.Lq = d->Lq; a.Lkv1 = d->Lkv1; a.Lkv2 = d->k2 ? d->Lkv2 : 0;
+  a.q_bs = d->q_bs; a.q_rs = d->q_rs; a.k1_bs = d->k1_bs; a.k1_rs = d->k1_rs;
+  a.v1_bs = d->v1_bs; a.v1_rs = d->v1_rs; a.k2_bs = d->k2_bs; a.k2_rs = d->k2_rs;
+  a.v2_bs = d->v2_bs; a.v2_rs = d->v2_rs; a.o_bs = d->o_bs; a.o_rs = d->o_rs;
+  a.kv2_div = d->kv2_batch_div > 0 ? d->kv2_batch_div : 1;
+  a.kv2_first = d->kv2_first_batch;
+  a.scale_log2e = d->scale * 1.4426950408889634f;
+  a.nqb = (d->Lq + 127) / 128;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->dtype == DT_F16) return launch_attn<_Float16>(a, d->head_dim, st);
+  if (d->dtype == DT_BF16) return launch_attn<__bf16>(a, d->head_dim, st);
+  return -22;
+}
+
+extern "C" int hallo_temporal_attention(const void* qkv, void* out, int B, int F, int HW, int C, int heads,
+                                        float scale, int dtype, void* stream) {
+  if (!qkv || !out || B <= 0 || F <= 0 || F > 32 || HW <= 0 || C <= 0 || heads <= 0) return -22;
+  if (C % heads || (C / heads) % 8) return -22;
+  const int hd = C / heads;
+  // heads per block: largest divisor of `heads` whose slab fits ~40 KB (>= 4 workgroups per CU)
+  int hpb = heads;
+  auto lds_for = [&](int g) { return (size_t)F * 3 * g * hd * 2 + (size_t)g * F * (F + 1) * sizeof(float); };
+  while (hpb > 1 && (lds_for(hpb) > 40 * 1024 || heads % hpb)) --hpb;
+  const size_t lds = lds_for(hpb);
+  if (lds > 64 * 1024) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(B * HW, heads / hpb), block(256);
+  const float sl = scale * 1.4426950408889634f;
+  if (dtype == DT_F16) {
+    hipLaunchKernelGGL((temporal_attn_kernel<_Float16>), grid, block, lds, st,
+                       reinterpret_cast<const _Float16*>(qkv), reinterpret_cast<_Float16*>(out), F, HW, C, hd, hpb, sl);
+  } else if (dtype == DT_BF16) {
+    hipLaunchKernelGGL((temporal_attn_kernel<__bf16>), grid, block, lds, st,
+                       reinterpret_cast<const __bf16*>(qkv), reinterpret_cast<__bf16*>(out), F, HW, C, hd, hpb, sl);
+  } else {
+    return -22;
+  }
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,84 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the Hallo denoising path.
+// Wave = 64 lanes; MFMA fragments follow the 32x32x16 layout:
+//   A: lane l holds A[i = l&31][k = (l>>5)*8 .. +7]
+//   B: lane l holds B[k = (l>>5)*8 .. +7][j = l&31]
+//   D: lane l holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31], r = 0..15
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hallo {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+enum { DT_F16 = 0, DT_BF16 = 1 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+
+template <typename T> struct Vec;
+template <> struct Vec<_Float16> {
+  using v8 = f16x8;
+  using v4 = f16x4;
+  static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Vec<__bf16> {
+  using v8 = bf16x8;
+  using v4 = bf16x4;
+  static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return static_cast<float>(x); }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return static_cast<T>(x); }
+
+// 16-byte (8 x T) global/LDS access helpers
+template <typename T> __device__ __forceinline__ typename Vec<T>::v8 ld8(const T* p) {
+  return *reinterpret_cast<const typename Vec<T>::v8*>(p);
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, typename Vec<T>::v8 v) {
+  *reinterpret_cast<typename Vec<T>::v8*>(p) = v;
+}
+template <typename T> __device__ __forceinline__ typename Vec<T>::v8 zero8() {
+  typename Vec<T>::v8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = static_cast<T>(0.0f);
+  return z;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a linear workgroup id: the dispatcher places block b on XCD b%8;
+// give each XCD a contiguous chunk of the tile space so neighbouring tiles share one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+}  // namespace hallo
+
+#define HALLO_CHECK_LAUNCH()                                    \
+  do {                                                          \
+    hipError_t e__ = hipGetLastError();                         \
+    if (e__ != hipSuccess) return -(int)e__ - 1000;             \
+  } while (0)

@@ -1,0 +1,460 @@
+// HBM-bound operators of the Hallo denoising path on token-major [frames, H*W, C] activations:
+// GroupNorm(+SiLU), LayerNorm(+positional encoding), row softmax, strided copies, layout
+// conversion at the pipeline boundary, timestep embedding and the fused CFG + DDIM update.
+// All loads/stores are 16-byte vectors (8 x fp16/bf16); statistics are fp32 (combined in fp64).
+#include "common.h"
+#include "../../include/hallo_amd.h"
+
+namespace hallo {
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm, pass 1: per-(frame, chunk) partial sum / sum of squares for each group.
+// grid (chunks, n_img); every thread owns one fixed 8-channel vector column and strides rows.
+// ------------------------------------------------------------------------------------------
+constexpr int GN_MAX_GROUPS = 32;
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ ws,
+                                                       int HW, int C, int groups, int rows_per_chunk) {
+  using V8 = typename Vec<T>::v8;
+  __shared__ float s_sum[GN_MAX_GROUPS], s_sq[GN_MAX_GROUPS];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, img = blockIdx.y, nchunks = gridDim.x;
+  const int vpr = C / 8;
+  const int cpg = C / groups;
+  if (tid < GN_MAX_GROUPS) { s_sum[tid] = 0.0f; s_sq[tid] = 0.0f; }
+  __syncthreads();
+  const int r_begin = chunk * rows_per_chunk;
+  const int r_end = min(HW, r_begin + rows_per_chunk);
+  // vector columns are distributed over threads; threads beyond a multiple of vpr take extra rows
+  const int tpr = vpr <= 256 ? vpr : 256;          // threads that span one row
+  const int row_lanes = 256 / tpr;                 // rows processed concurrently
+  const int my_row = tid / tpr, my_v0 = tid % tpr;
+  if (my_row < row_lanes) {
+    for (int v = my_v0; v < vpr; v += tpr) {
+      float a[8], q[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a[e] = 0.0f; q[e] = 0.0f; }
+      const T* base = x + ((long)img * HW) * C + v * 8;
+      for (int r = r_begin + my_row; r < r_end; r += row_lanes) {
+        V8 val = ld8<T>(base + (long)r * C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = to_f32(val[e]); a[e] += f; q[e] += f * f; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int g = (v * 8 + e) / cpg;
+        atomicAdd(&s_sum[g], a[e]);
+        atomicAdd(&s_sq[g], q[e]);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < groups) {
+    float* o = ws + (((long)img * nchunks + chunk) * groups + tid) * 2;
+    o[0] = s_sum[tid];
+    o[1] = s_sq[tid];
+  }
+}
+
+// GroupNorm, pass 2: finalise the statistics (fp64 combine) and apply scale/shift (+SiLU).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                       const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                       const float* __restrict__ ws, int HW, int C, int groups,
+                                                       int nchunks, int rows_per_block, float eps, int silu) {
+  using V8 = typename Vec<T>::v8;
+  __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
+  const int tid = threadIdx.x;
+  const int img = blockIdx.y;
+  const int cpg = C / groups;
+  if (tid < groups) {
+    double s = 0.0, q = 0.0;
+    for (int c = 0; c < nchunks; ++c) {
+      const float* w = ws + (((long)img * nchunks + c) * groups + tid) * 2;
+      s += (double)w[0];
+      q += (double)w[1];
+    }
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int vpr = C / 8;
+  const long r_begin = (long)blockIdx.x * rows_per_block;
+  const long r_end = min((long)HW, r_begin + rows_per_block);
+  const long total = (r_end - r_begin) * vpr;
+  const T* xb = x + ((long)img * HW + r_begin) * C;
+  T* yb = y + ((long)img * HW + r_begin) * C;
+  for (long u = tid; u < total; u += 256) {
+    const int v = (int)(u % vpr);
+    const int c0 = v * 8;
+    V8 val = ld8<T>(xb + u * 8);
+    V8 g8 = ld8<T>(gamma + c0), b8 = ld8<T>(beta + c0);
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (c0 + e) / cpg;
+      float f = (to_f32(val[e]) - s_mean[g]) * s_rstd[g];
+      f = f * to_f32(g8[e]) + to_f32(b8[e]);
+      if (silu) f = silu_f(f);
+      o[e] = from_f32<T>(f);
+    }
+    st8<T>(yb + u * 8, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers (C <= 8*64*MAXV), two-pass statistics.
+// ------------------------------------------------------------------------------------------
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                        const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                        const float* __restrict__ pe, long rows, int C, float eps,
+                                                        int pe_rpp, int pe_len) {
+  using V8 = typename Vec<T>::v8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const int vpr = C / 8;
+  const T* xr = x + row * C;
+  float v[MAXV][8];
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < vpr) {
+      V8 t = ld8<T>(xr + vi * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = to_f32(t[e]); sum += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.0f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < vpr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  const float* per = pe ? pe + (long)((row / pe_rpp) % pe_len) * C : nullptr;
+  T* yr = y + row * C;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int vi = lane + 64 * i;
+    if (vi < vpr) {
+      V8 g8 = ld8<T>(gamma + vi * 8), b8 = ld8<T>(beta + vi * 8);
+      V8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (v[i][e] - mean) * rstd * to_f32(g8[e]) + to_f32(b8[e]);
+        if (per) {
+          // the reference adds the PE to the already-rounded LayerNorm output (motion_module.py:459)
+          f = to_f32(from_f32<T>(f)) + per[vi * 8 + e];
+        }
+        o[e] = from_f32<T>(f);
+      }
+      st8<T>(yr + vi * 8, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Row softmax (fp32 in, T out): one workgroup per row.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, T* __restrict__ y,
+                                                           int cols, float scale_log2e) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = x + (long)blockIdx.x * cols;
+  T* yr = y + (long)blockIdx.x * cols;
+  float mx = -1e30f;
+  for (int c = tid * 4; c < cols; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2e;
+  __syncthreads();
+  float sum = 0.0f;
+  for (int c = tid * 4; c < cols; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    sum += exp2f(v.x * scale_log2e - mx) + exp2f(v.y * scale_log2e - mx) + exp2f(v.z * scale_log2e - mx) +
+           exp2f(v.w * scale_log2e - mx);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (int c = tid * 4; c < cols; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    typename Vec<T>::v4 o;
+    o[0] = from_f32<T>(exp2f(v.x * scale_log2e - mx) * inv);
+    o[1] = from_f32<T>(exp2f(v.y * scale_log2e - mx) * inv);
+    o[2] = from_f32<T>(exp2f(v.z * scale_log2e - mx) * inv);
+    o[3] = from_f32<T>(exp2f(v.w * scale_log2e - mx) * inv);
+    *reinterpret_cast<typename Vec<T>::v4*>(yr + c) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Strided 2-D copy in 16-byte vectors (skip concat / motion-frame concat).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy2d_kernel(const uint4* __restrict__ src, long src_pitch_v,
+                                                     uint4* __restrict__ dst, long dst_pitch_v, long rows,
+                                                     int width_v) {
+  const long total = rows * width_v;
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+    const long r = u / width_v;
+    const int c = (int)(u - r * width_v);
+    dst[r * dst_pitch_v + c] = src[r * src_pitch_v + c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Boundary layout conversion.
+// ------------------------------------------------------------------------------------------
+template <typename T, typename S>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const S* __restrict__ x, T* __restrict__ y, int C,
+                                                           int HW, int Cpad) {
+  // grid (ceil(HW/256), n); small C (3, 4, 8): each thread writes one token's Cpad channels
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  T* o = y + ((long)n * HW + p) * Cpad;
+  for (int c = 0; c < Cpad; ++c) {
+    const float f = c < C ? (float)x[((long)n * C + c) * HW + p] : 0.0f;
+    o[c] = from_f32<T>(f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const T* __restrict__ x, float* __restrict__ y,
+                                                               int C, int HW, long ldx, float mul, float add,
+                                                               float lo, float hi) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const T* i = x + ((long)n * HW + p) * ldx;
+  for (int c = 0; c < C; ++c) {
+    float f = to_f32(i[c]) * mul + add;
+    f = fminf(fmaxf(f, lo), hi);
+    y[((long)n * C + c) * HW + p] = f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Timestep embedding: [cos | sin] (flip_sin_to_cos=True, downscale_freq_shift=0).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, T* __restrict__ out, int dim) {
+  const int b = blockIdx.x;
+  const int half = dim / 2;
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    const float freq = expf(-logf(10000.0f) * (float)i / (float)half);
+    const float a = t[b] * freq;
+    out[(long)b * dim + i] = from_f32<T>(cosf(a));
+    out[(long)b * dim + half + i] = from_f32<T>(sinf(a));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// CFG combine + DDIM v-prediction step (eta = 0), fp32 latents updated in place.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const T* __restrict__ mo, long ldm, float* __restrict__ lat,
+                                                       T* __restrict__ nxt, long ldn, long rows, int C, int cfg,
+                                                       float gs, float sa_t, float sb_t, float sa_p, float sb_p) {
+  const long total = rows * C;
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+    const long r = u / C;
+    const int c = (int)(u - r * C);
+    float v;
+    if (cfg) {
+      const float vu = to_f32(mo[r * ldm + c]);
+      const float vc = to_f32(mo[(rows + r) * ldm + c]);
+      v = vu + gs * (vc - vu);
+    } else {
+      v = to_f32(mo[r * ldm + c]);
+    }
+    const float xs = lat[u];
+    const float x0 = sa_t * xs - sb_t * v;
+    const float ep = sa_t * v + sb_t * xs;
+    const float xp = sa_p * x0 + sb_p * ep;
+    lat[u] = xp;
+    if (nxt) {
+      const T o = from_f32<T>(xp);
+      nxt[r * ldn + c] = o;
+      if (cfg) nxt[(rows + r) * ldn + c] = o;
+    }
+  }
+}
+
+}  // namespace hallo
+
+using namespace hallo;
+
+extern "C" int hallo_abi_version(void) { return 1; }
+
+extern "C" int hallo_groupnorm_chunks(int HW) {
+  int c = (HW + 255) / 256;
+  if (c > 64) c = 64;
+  if (c < 1) c = 1;
+  return c;
+}
+
+template <typename T>
+static int launch_groupnorm(const void* x, void* y, const void* gamma, const void* beta, float* ws, int n_img,
+                            int HW, int C, int groups, float eps, int silu, hipStream_t st) {
+  const int nchunks = hallo_groupnorm_chunks(HW);
+  const int rpc = (HW + nchunks - 1) / nchunks;
+  hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nchunks, n_img), dim3(256), 0, st, reinterpret_cast<const T*>(x), ws,
+                     HW, C, groups, rpc);
+  // apply: ~16 KB of data per 256-thread block
+  int rows_per_block = (8192 * 2) / (C * 2);
+  if (rows_per_block < 1) rows_per_block = 1;
+  const int nb = (HW + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nb, n_img), dim3(256), 0, st, reinterpret_cast<const T*>(x),
+                     reinterpret_cast<T*>(y), reinterpret_cast<const T*>(gamma), reinterpret_cast<const T*>(beta), ws,
+                     HW, C, groups, nchunks, rows_per_block, eps, silu);
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hallo_groupnorm_nhwc(const void* x, void* y, const void* gamma, const void* beta, float* workspace,
+                                    int n_img, int HW, int C, int groups, float eps, int silu, int dtype,
+                                    void* stream) {
+  if (!x || !y || !gamma || !beta || !workspace) return -22;
+  if (n_img <= 0 || HW <= 0 || C <= 0 || (C & 7) || groups <= 0 || groups > GN_MAX_GROUPS || C % groups) return -22;
+  if (n_img > 65535) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == DT_F16) return launch_groupnorm<_Float16>(x, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, st);
+  if (dtype == DT_BF16) return launch_groupnorm<__bf16>(x, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, st);
+  return -22;
+}
+
+template <typename T>
+static int launch_layernorm(const void* x, void* y, const void* g, const void* b, const float* pe, long rows, int C,
+                            float eps, int rpp, int plen, hipStream_t st) {
+  const int vpr = C / 8;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  const T* xx = reinterpret_cast<const T*>(x);
+  T* yy = reinterpret_cast<T*>(y);
+  const T* gg = reinterpret_cast<const T*>(g);
+  const T* bb = reinterpret_cast<const T*>(b);
+  if (vpr <= 64) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, st, xx, yy, gg, bb, pe, rows, C, eps, rpp, plen);
+  else if (vpr <= 128) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, st, xx, yy, gg, bb, pe, rows, C, eps, rpp, plen);
+  else if (vpr <= 192) hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, st, xx, yy, gg, bb, pe, rows, C, eps, rpp, plen);
+  else return -22;
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hallo_layernorm(const void* x, void* y, const void* gamma, const void* beta, const float* pe, int rows,
+                               int C, float eps, int pe_rows_per_pos, int pe_len, int dtype, void* stream) {
+  if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || (C & 7) || C > 1536) return -22;
+  if (pe && (pe_rows_per_pos <= 0 || pe_len <= 0)) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int rpp = pe ? pe_rows_per_pos : 1, plen = pe ? pe_len : 1;
+  if (dtype == DT_F16) return launch_layernorm<_Float16>(x, y, gamma, beta, pe, rows, C, eps, rpp, plen, st);
+  if (dtype == DT_BF16) return launch_layernorm<__bf16>(x, y, gamma, beta, pe, rows, C, eps, rpp, plen, st);
+  return -22;
+}
+
+extern "C" int hallo_softmax_rows(const float* x, void* y, int rows, int cols, float scale, int dtype, void* stream) {
+  if (!x || !y || rows <= 0 || cols <= 0 || (cols & 3)) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const float sl = scale * 1.4426950408889634f;
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL((softmax_rows_kernel<_Float16>), dim3(rows), dim3(256), 0, st, x, reinterpret_cast<_Float16*>(y), cols, sl);
+  else if (dtype == DT_BF16)
+    hipLaunchKernelGGL((softmax_rows_kernel<__bf16>), dim3(rows), dim3(256), 0, st, x, reinterpret_cast<__bf16*>(y), cols, sl);
+  else return -22;
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hallo_copy2d(const void* src, int64_t src_pitch, void* dst, int64_t dst_pitch, int64_t rows, int width,
+                            int dtype, void* stream) {
+  (void)dtype;  // both storage types are 2 bytes
+  if (!src || !dst || rows <= 0 || width <= 0) return -22;
+  if ((width & 7) || (src_pitch & 7) || (dst_pitch & 7)) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long total = rows * (width / 8);
+  long nb = (total + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)nb), dim3(256), 0, st, reinterpret_cast<const uint4*>(src),
+                     (long)(src_pitch / 8), reinterpret_cast<uint4*>(dst), (long)(dst_pitch / 8), (long)rows, width / 8);
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hallo_nchw_to_nhwc(const void* x, void* y, int n, int C, int HW, int Cpad, int src_f32, int dtype,
+                                  void* stream) {
+  if (!x || !y || n <= 0 || C <= 0 || HW <= 0 || Cpad < C || n > 65535) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((HW + 255) / 256, n), block(256);
+  if (dtype == DT_F16) {
+    if (src_f32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<_Float16, float>), grid, block, 0, st, reinterpret_cast<const float*>(x), reinterpret_cast<_Float16*>(y), C, HW, Cpad);
+    else hipLaunchKernelGGL((nchw_to_nhwc_kernel<_Float16, _Float16>), grid, block, 0, st, reinterpret_cast<const _Float16*>(x), reinterpret_cast<_Float16*>(y), C, HW, Cpad);
+  } else if (dtype == DT_BF16) {
+    if (src_f32) hipLaunchKernelGGL((nchw_to_nhwc_kernel<__bf16, float>), grid, block, 0, st, reinterpret_cast<const float*>(x), reinterpret_cast<__bf16*>(y), C, HW, Cpad);
+    else hipLaunchKernelGGL((nchw_to_nhwc_kernel<__bf16, __bf16>), grid, block, 0, st, reinterpret_cast<const __bf16*>(x), reinterpret_cast<__bf16*>(y), C, HW, Cpad);
+  } else return -22;
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hallo_nhwc_to_nchw_f32(const void* x, float* y, int n, int C, int HW, int64_t ldx, float mul, float add,
+                                      float lo, float hi, int dtype, void* stream) {
+  if (!x || !y || n <= 0 || C <= 0 || HW <= 0 || ldx < C || n > 65535) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((HW + 255) / 256, n), block(256);
+  if (dtype == DT_F16) hipLaunchKernelGGL((nhwc_to_nchw_f32_kernel<_Float16>), grid, block, 0, st, reinterpret_cast<const _Float16*>(x), y, C, HW, (long)ldx, mul, add, lo, hi);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL((nhwc_to_nchw_f32_kernel<__bf16>), grid, block, 0, st, reinterpret_cast<const __bf16*>(x), y, C, HW, (long)ldx, mul, add, lo, hi);
+  else return -22;
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hallo_timestep_embedding(const float* t, void* out, int batch, int dim, int dtype, void* stream) {
+  if (!t || !out || batch <= 0 || dim <= 0 || (dim & 1)) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == DT_F16) hipLaunchKernelGGL((timestep_embedding_kernel<_Float16>), dim3(batch), dim3(256), 0, st, t, reinterpret_cast<_Float16*>(out), dim);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL((timestep_embedding_kernel<__bf16>), dim3(batch), dim3(256), 0, st, t, reinterpret_cast<__bf16*>(out), dim);
+  else return -22;
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hallo_cfg_ddim_step(const void* model_out, int64_t ldm, float* latents, void* next_in, int64_t ldn,
+                                   int rows, int C, int cfg, float guidance_scale, float alpha_t, float alpha_prev,
+                                   int dtype, void* stream) {
+  if (!model_out || !latents || rows <= 0 || C <= 0 || ldm < C || (next_in && ldn < C)) return -22;
+  if (alpha_t < 0.0f || alpha_t > 1.0f || alpha_prev < 0.0f || alpha_prev > 1.0f) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const float sa_t = sqrtf(alpha_t), sb_t = sqrtf(1.0f - alpha_t);
+  const float sa_p = sqrtf(alpha_prev), sb_p = sqrtf(1.0f - alpha_prev);
+  const long total = (long)rows * C;
+  long nb = (total + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  if (dtype == DT_F16)
+    hipLaunchKernelGGL((cfg_ddim_kernel<_Float16>), dim3((unsigned)nb), dim3(256), 0, st, reinterpret_cast<const _Float16*>(model_out), (long)ldm, latents, reinterpret_cast<_Float16*>(next_in), (long)ldn, (long)rows, C, cfg, guidance_scale, sa_t, sb_t, sa_p, sb_p);
+  else if (dtype == DT_BF16)
+    hipLaunchKernelGGL((cfg_ddim_kernel<__bf16>), dim3((unsigned)nb), dim3(256), 0, st, reinterpret_cast<const __bf16*>(model_out), (long)ldm, latents, reinterpret_cast<__bf16*>(next_in), (long)ldn, (long)rows, C, cfg, guidance_scale, sa_t, sb_t, sa_p, sb_p);
+  else return -22;
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,268 @@
+"""Thin Python wrappers over the C ABI of libhallo_amd.so.
+
+PyTorch is used only for device memory (tensor allocation / data_ptr) and the current HIP
+stream; every computation goes through the hand-written gfx950 kernels.  Activations are
+token-major: [frames, H*W, C] with C contiguous.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _l
+
+F16, BF16 = _l.F16, _l.BF16
+ACT_NONE, ACT_SILU, ACT_RELU = _l.ACT_NONE, _l.ACT_SILU, _l.ACT_RELU
+
+
+def dtype_code(dtype):
+    if dtype == torch.float16:
+        return F16
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"hallo_amd kernels store activations/weights as fp16 or bf16, got {dtype}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _l.HalloLibraryError("hallo_amd operators need device (HIP) tensors; there is no CPU path")
+
+
+def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, act=ACT_NONE, geglu=False,
+         bias2=None, bias2_rows_per_group=0, out_f32=False, bias_per_row=False):
+    """out[M,N] = act(alpha * rowscale * (a[M,K] @ w[N,K]^T + bias) + residual).
+
+    a may be a 2-D view with arbitrary row stride (last dim contiguous).  geglu: w is [2N,K]."""
+    _chk_dev(a, w)
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
+    M, K = a.shape
+    N = w.shape[0] // 2 if geglu else w.shape[0]
+    assert w.shape[1] == K, (a.shape, w.shape)
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    assert out.stride(1) == 1 and out.shape[0] == M and out.shape[1] == N
+    d = _l.GemmDesc()
+    d.A, d.B, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = a.stride(0), w.stride(0), out.stride(0)
+    d.batch = 1
+    d.stride_a = d.stride_b = d.stride_c = d.stride_r = 0
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.bias_per_row = 1 if bias_per_row else 0
+    d.bias2 = bias2.data_ptr() if bias2 is not None else None
+    d.bias2_rows_per_group = bias2_rows_per_group
+    d.rowscale = rowscale.data_ptr() if rowscale is not None else None
+    if rowscale is not None:
+        assert rowscale.dtype == torch.float32 and rowscale.numel() == M
+    if residual is not None:
+        assert residual.stride(1) == 1 and residual.shape == out.shape
+        d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+    else:
+        d.residual, d.ldr = None, 0
+    d.alpha, d.act, d.geglu, d.out_f32 = float(alpha), act, 1 if geglu else 0, 1 if out_f32 else 0
+    d.dtype = dtype_code(a.dtype)
+    _l.check(_l.load().hallo_gemm(C.byref(d), _stream()), "hallo_gemm")
+    return out
+
+
+def gemm_batched(a, w, out, *, out_f32=False, alpha=1.0, bias=None, bias_per_row=False):
+    """Strided-batched out[b] = alpha * (a[b] @ w[b]^T + bias); a [B,M,K], w [B,N,K], out [B,M,N]."""
+    _chk_dev(a, w, out)
+    Bn, M, K = a.shape
+    N = w.shape[1]
+    d = _l.GemmDesc()
+    d.A, d.B, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = a.stride(1), w.stride(1), out.stride(1)
+    d.batch = Bn
+    d.stride_a, d.stride_b, d.stride_c, d.stride_r = a.stride(0), w.stride(0), out.stride(0), 0
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.bias_per_row = 1 if bias_per_row else 0
+    d.bias2, d.bias2_rows_per_group, d.rowscale, d.residual, d.ldr = None, 0, None, None, 0
+    d.alpha, d.act, d.geglu, d.out_f32 = float(alpha), ACT_NONE, 0, 1 if out_f32 else 0
+    d.dtype = dtype_code(a.dtype)
+    _l.check(_l.load().hallo_gemm(C.byref(d), _stream()), "hallo_gemm(batched)")
+    return out
+
+
+def conv3x3(x, w, bias, n_img, H, W, *, stride=1, pad_t=1, pad_l=1, out_hw=None, upsample=False, bias2=None,
+            bias2_rows_per_group=0, residual=None, alpha=1.0, act=ACT_NONE, out=None):
+    """x [n_img, H*W, Cin] -> [n_img, OH*OW, Cout]; w [Cout, 3, 3, Cin] (flattened [Cout, 9*Cin])."""
+    _chk_dev(x, w)
+    Cin = x.shape[-1]
+    Cout = w.shape[0]
+    assert x.is_contiguous() and w.is_contiguous() and w.numel() == Cout * 9 * Cin
+    VH, VW = (2 * H, 2 * W) if upsample else (H, W)
+    if out_hw is None:
+        OH = (VH + 2 * pad_t - 3) // stride + 1
+        OW = (VW + 2 * pad_l - 3) // stride + 1
+    else:
+        OH, OW = out_hw
+    if out is None:
+        out = torch.empty((n_img, OH * OW, Cout), device=x.device, dtype=x.dtype)
+    d = _l.ConvDesc()
+    d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.n_img, d.H, d.W, d.Cin, d.Cout, d.OH, d.OW = n_img, H, W, Cin, Cout, OH, OW
+    d.stride, d.pad_t, d.pad_l, d.upsample = stride, pad_t, pad_l, 1 if upsample else 0
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.bias2 = bias2.data_ptr() if bias2 is not None else None
+    d.bias2_rows_per_group = bias2_rows_per_group
+    if residual is not None:
+        assert residual.is_contiguous()
+        d.residual, d.ldr = residual.data_ptr(), residual.shape[-1]
+    else:
+        d.residual, d.ldr = None, 0
+    d.ldy = out.stride(-2)
+    d.alpha, d.act, d.dtype = float(alpha), act, dtype_code(x.dtype)
+    _l.check(_l.load().hallo_conv3x3_nhwc(C.byref(d), _stream()), "hallo_conv3x3_nhwc")
+    return out
+
+
+def attention(q, k1, v1, heads, *, k2=None, v2=None, kv2_batch_div=1, kv2_first_batch=0, out=None, scale=None):
+    """softmax(q k^T * scale) v over up to two key/value segments.
+
+    q [B, Lq, C], k1/v1 [B, Lkv1, C], k2/v2 [B2, Lkv2, C] are views with contiguous last dim
+    (e.g. column slices of a fused projection buffer); C = heads * head_dim."""
+    _chk_dev(q, k1, v1)
+    B, Lq, Cq = q.shape
+    hd = Cq // heads
+    if out is None:
+        out = torch.empty((B, Lq, Cq), device=q.device, dtype=q.dtype)
+    d = _l.AttnDesc()
+    d.q, d.k1, d.v1, d.o = q.data_ptr(), k1.data_ptr(), v1.data_ptr(), out.data_ptr()
+    d.k2 = k2.data_ptr() if k2 is not None else None
+    d.v2 = v2.data_ptr() if v2 is not None else None
+    d.batch, d.heads, d.head_dim, d.Lq, d.Lkv1 = B, heads, hd, Lq, k1.shape[1]
+    d.Lkv2 = k2.shape[1] if k2 is not None else 0
+    for t in (q, k1, v1, out):
+        assert t.stride(2) == 1
+    d.q_bs, d.q_rs = q.stride(0), q.stride(1)
+    d.k1_bs, d.k1_rs = (k1.stride(0) if k1.shape[0] > 1 else 0), k1.stride(1)
+    d.v1_bs, d.v1_rs = (v1.stride(0) if v1.shape[0] > 1 else 0), v1.stride(1)
+    if k2 is not None:
+        assert k2.stride(2) == 1 and v2.stride(2) == 1
+        d.k2_bs, d.k2_rs = (k2.stride(0) if k2.shape[0] > 1 else 0), k2.stride(1)
+        d.v2_bs, d.v2_rs = (v2.stride(0) if v2.shape[0] > 1 else 0), v2.stride(1)
+    else:
+        d.k2_bs = d.k2_rs = d.v2_bs = d.v2_rs = 0
+    d.o_bs, d.o_rs = out.stride(0), out.stride(1)
+    d.kv2_batch_div, d.kv2_first_batch = kv2_batch_div, kv2_first_batch
+    d.scale = float(scale if scale is not None else hd ** -0.5)
+    d.dtype = dtype_code(q.dtype)
+    _l.check(_l.load().hallo_attention(C.byref(d), _stream()), "hallo_attention")
+    return out
+
+
+def temporal_attention(qkv, B, F, HW, Cdim, heads, *, out=None, scale=None):
+    """qkv [B*F, HW, 3C] -> out [B*F, HW, C]: per-pixel attention over the F axis."""
+    _chk_dev(qkv)
+    assert qkv.is_contiguous() and qkv.shape[-1] == 3 * Cdim
+    if out is None:
+        out = torch.empty((B * F, HW, Cdim), device=qkv.device, dtype=qkv.dtype)
+    hd = Cdim // heads
+    sc = float(scale if scale is not None else hd ** -0.5)
+    _l.check(_l.load().hallo_temporal_attention(_p(qkv), _p(out), B, F, HW, Cdim, heads, sc, dtype_code(qkv.dtype),
+                                                _stream()), "hallo_temporal_attention")
+    return out
+
+
+_gn_ws = {}
+
+
+def groupnorm(x, gamma, beta, n_img, HW, groups, eps, *, silu=False, out=None):
+    """Per-frame GroupNorm (+SiLU) on x [n_img, HW, C]."""
+    _chk_dev(x)
+    Cdim = x.shape[-1]
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    lib = _l.load()
+    need = n_img * lib.hallo_groupnorm_chunks(HW) * groups * 2
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 16), device=x.device, dtype=torch.float32)
+        _gn_ws[key] = ws
+    _l.check(lib.hallo_groupnorm_nhwc(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), n_img, HW, Cdim, groups, float(eps),
+                                      1 if silu else 0, dtype_code(x.dtype), _stream()), "hallo_groupnorm_nhwc")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, *, pe=None, pe_rows_per_pos=1, pe_len=1, out=None):
+    """Row LayerNorm on x [..., C] (+ fp32 positional-encoding table pe [pe_len, C])."""
+    _chk_dev(x)
+    Cdim = x.shape[-1]
+    assert x.is_contiguous()
+    rows = x.numel() // Cdim
+    if out is None:
+        out = torch.empty_like(x)
+    _l.check(_l.load().hallo_layernorm(_p(x), _p(out), _p(gamma), _p(beta), _p(pe), rows, Cdim, float(eps),
+                                       pe_rows_per_pos, pe_len, dtype_code(x.dtype), _stream()), "hallo_layernorm")
+    return out
+
+
+def softmax_rows(x, out, scale):
+    _chk_dev(x, out)
+    rows, cols = x.shape[-2] * (x.numel() // (x.shape[-1] * x.shape[-2])), x.shape[-1]
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+    _l.check(_l.load().hallo_softmax_rows(_p(x), _p(out), rows, cols, float(scale), dtype_code(out.dtype), _stream()),
+             "hallo_softmax_rows")
+    return out
+
+
+def copy2d(src, dst, rows, width):
+    """dst[r, :width] = src[r, :width]; src/dst are 2-D views (row pitch = stride(0))."""
+    _chk_dev(src, dst)
+    _l.check(_l.load().hallo_copy2d(_p(src), src.stride(0), _p(dst), dst.stride(0), rows, width, dtype_code(dst.dtype),
+                                    _stream()), "hallo_copy2d")
+    return dst
+
+
+def nchw_to_nhwc(x, n, Cdim, HW, Cpad, dtype):
+    """x [n, C, HW] (fp32 or `dtype`) -> [n, HW, Cpad] in `dtype`, padded channels zero."""
+    _chk_dev(x)
+    assert x.is_contiguous()
+    out = torch.empty((n, HW, Cpad), device=x.device, dtype=dtype)
+    src_f32 = 1 if x.dtype == torch.float32 else 0
+    if not src_f32:
+        assert x.dtype == dtype
+    _l.check(_l.load().hallo_nchw_to_nhwc(_p(x), _p(out), n, Cdim, HW, Cpad, src_f32, dtype_code(dtype), _stream()),
+             "hallo_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw_f32(x, n, Cdim, HW, *, mul=1.0, add=0.0, lo=-3.0e38, hi=3.0e38):
+    _chk_dev(x)
+    out = torch.empty((n, Cdim, HW), device=x.device, dtype=torch.float32)
+    _l.check(_l.load().hallo_nhwc_to_nchw_f32(_p(x), _p(out), n, Cdim, HW, x.stride(-2), float(mul), float(add), float(lo),
+                                              float(hi), dtype_code(x.dtype), _stream()), "hallo_nhwc_to_nchw_f32")
+    return out
+
+
+def timestep_embedding(t, dim, dtype):
+    """t fp32 [B] -> [B, dim] = [cos | sin] (diffusers Timesteps with flip_sin_to_cos)."""
+    _chk_dev(t)
+    assert t.dtype == torch.float32
+    out = torch.empty((t.numel(), dim), device=t.device, dtype=dtype)
+    _l.check(_l.load().hallo_timestep_embedding(_p(t), _p(out), t.numel(), dim, dtype_code(dtype), _stream()),
+             "hallo_timestep_embedding")
+    return out
+
+
+def cfg_ddim_step(model_out, latents, next_in, rows, Cdim, cfg, guidance_scale, alpha_t, alpha_prev):
+    """In-place DDIM (eta=0, v-prediction) update of fp32 latents [rows, C] from model_out [(2)rows, ldm]."""
+    _chk_dev(model_out, latents)
+    assert latents.dtype == torch.float32 and latents.is_contiguous()
+    _l.check(_l.load().hallo_cfg_ddim_step(_p(model_out), model_out.stride(-2), _p(latents), _p(next_in),
+                                           next_in.stride(-2) if next_in is not None else 0, rows, Cdim,
+                                           1 if cfg else 0, float(guidance_scale), float(alpha_t), float(alpha_prev),
+                                           dtype_code(model_out.dtype), _stream()), "hallo_cfg_ddim_step")
+    return latents

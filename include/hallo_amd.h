@@ -1,0 +1,189 @@
+/*
+ * hallo_amd.h -- C ABI of libhallo_amd.so: the gfx950 (MI355X) operator library behind the
+ * Hallo denoising hot path.
+ *
+ * The reference (fudan-generative-vision/hallo) has no C/FFI boundary: its operator seam is
+ * the diffusers attention-processor protocol and torch module calls.  Each entry point below
+ * names the reference call sites it replaces (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - extern "C", plain device pointers and sizes, no torch types.
+ *   - return 0 on success, -22 (EINVAL) on bad arguments, <= -1000 for a HIP launch error.
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream.
+ *   - no allocation inside; the caller owns all buffers for the duration of the call.
+ *   - dtype: HALLO_F16 / HALLO_BF16 select the storage type of activations and weights;
+ *     all accumulation is fp32.
+ *   - activations are token-major ("NHWC"): [frames, H*W, C] with C contiguous.
+ */
+#ifndef HALLO_AMD_H
+#define HALLO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HALLO_F16 0
+#define HALLO_BF16 1
+
+#define HALLO_ACT_NONE 0
+#define HALLO_ACT_SILU 1
+#define HALLO_ACT_RELU 2
+
+int hallo_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * hallo_gemm: C[M,N] = act( alpha * rowscale[m] * (A[M,K] . W[N,K]^T + bias) + residual )
+ * Replaces torch Linear / 1x1 Conv2d everywhere on the path:
+ *   Attention.to_q/to_k/to_v/to_out (diffusers, imported hallo/models/attention.py:22-23),
+ *   Transformer3DModel.proj_in/proj_out (hallo/models/transformer_3d.py:199,242),
+ *   TemporalTransformer3DModel.proj_in/proj_out (hallo/models/motion_module.py:295,306),
+ *   ResnetBlock3D.conv_shortcut / time_emb_proj (hallo/models/resnet.py:390-408),
+ *   zero_conv_full/face/lip + mask multiply + motion_scale sum (hallo/models/attention.py:846-903),
+ *   TimestepEmbedding (hallo/models/unet_3d.py:588), ImageProjModel / AudioProjModel Linears.
+ * geglu=1: W holds 2N rows (value rows then gate rows), output is value * gelu_erf(gate)
+ *   = diffusers FeedForward/GEGLU (hallo/models/attention.py:601,905; motion_module.py:420).
+ * batch>1 with element strides gives a strided-batched GEMM (VAE mid-block attention).
+ * K, lda, ldb must be multiples of 8; pointers 16-byte aligned.
+ */
+typedef struct hallo_gemm_desc {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  int batch;
+  int64_t stride_a, stride_b, stride_c, stride_r;
+  const void* bias;          /* [N] (geglu: [2N]); [M] if bias_per_row */
+  int bias_per_row;
+  const void* bias2;         /* [M / bias2_rows_per_group, N], e.g. per-frame time embedding */
+  int bias2_rows_per_group;
+  const float* rowscale;     /* [M] fp32, e.g. the audio attention masks */
+  const void* residual;      /* [M,N] with leading dimension ldr (may alias C) */
+  int64_t ldr;
+  float alpha;
+  int act;
+  int geglu;
+  int out_f32;               /* write C as fp32 instead of dtype */
+  int dtype;
+} hallo_gemm_desc;
+int hallo_gemm(const hallo_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * hallo_conv3x3_nhwc: implicit-GEMM 3x3 convolution on token-major activations.
+ *   y[n,oy,ox,:] = act( alpha * (sum_{ky,kx,c} x[n, oy*stride+ky-pad_t, ox*stride+kx-pad_l, c]
+ *                                 * w[:,ky,kx,c] + bias + bias2[n-group]) + residual )
+ * w is [Cout, 3, 3, Cin] (the torch [Cout,Cin,3,3] weight permuted once at load time).
+ * upsample=1 folds a nearest 2x upsample of x into the gather (Upsample3D, resnet.py:166-183).
+ * Replaces InflatedConv3d.forward (hallo/models/resnet.py:50-66) at conv_in/conv_out
+ * (unet_3d.py:603,710), ResnetBlock3D.conv1/conv2 (resnet.py:388,405), Downsample3D
+ * (resnet.py:250), FaceLocator (face_locator.py:94-113) and the AutoencoderKL convs.
+ * Cin must be a multiple of 8 (pad the channel axis with zeros otherwise).
+ */
+typedef struct hallo_conv_desc {
+  const void* x; const void* w; void* y;
+  int n_img, H, W, Cin, Cout, OH, OW;
+  int stride, pad_t, pad_l, upsample;
+  const void* bias;          /* [Cout] or null */
+  const void* bias2;         /* [n_groups, Cout] or null (time embedding per batch entry) */
+  int bias2_rows_per_group;  /* output rows (pixels) per bias2 row */
+  const void* residual;      /* [n_img*OH*OW, Cout] (ld = ldr) or null */
+  int64_t ldr;
+  int64_t ldy;               /* leading dimension of y, 0 = Cout */
+  float alpha;
+  int act;
+  int dtype;
+} hallo_conv_desc;
+int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * hallo_attention: flash-style softmax(Q K^T * scale) V with up to two key/value segments.
+ * Replaces diffusers AttnProcessor2_0 -> F.scaled_dot_product_attention at:
+ *   - the reference-augmented spatial self-attention (K/V = [self ; ReferenceNet bank],
+ *     hallo/models/mutual_self_attention.py:253-263) including the CFG rule that the
+ *     unconditional batch entries attend to themselves only (:264-284): segment 2 is skipped
+ *     for batch index < kv2_first_batch;
+ *   - the audio block's spatial self-attention (hallo/models/attention.py:828-831);
+ *   - the face-token cross-attention (mutual_self_attention.py:296-303) and the three
+ *     hierarchical audio cross-attentions (attention.py:846-884) with Lkv = 4 / 32.
+ * Layouts (element strides): q[b, i, h*hd + d] at q + b*q_bs + i*q_rs + h*hd + d; same for
+ * k1/v1 (Lkv1 rows) and k2/v2 (Lkv2 rows; batch index b / kv2_batch_div), o (row stride o_rs).
+ * head_dim in {40, 80, 160}.  heads*head_dim contiguous per row.
+ */
+typedef struct hallo_attn_desc {
+  const void* q; const void* k1; const void* v1; const void* k2; const void* v2; void* o;
+  int batch, heads, head_dim, Lq, Lkv1, Lkv2;
+  int64_t q_bs, q_rs, k1_bs, k1_rs, v1_bs, v1_rs, k2_bs, k2_rs, v2_bs, v2_rs, o_bs, o_rs;
+  int kv2_batch_div;    /* segment-2 batch index = b / kv2_batch_div (frames share one bank) */
+  int kv2_first_batch;  /* batches below this index skip segment 2 (CFG uncond half) */
+  float scale;          /* head_dim^-0.5 */
+  int dtype;
+} hallo_attn_desc;
+int hallo_attention(const hallo_attn_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * hallo_temporal_attention: per-pixel attention over the frame axis (F' <= 32 tokens).
+ * Replaces VersatileAttention.forward (hallo/models/motion_module.py:553-609): the
+ * "(b f) d c -> (b d) f c" rearranges, AttnProcessor SDPA over f and the inverse rearrange.
+ * qkv: [B*F', HW, 3*C] rows of [q | k | v] (the fused projection of norm(x)+PE), out: [B*F', HW, C].
+ */
+int hallo_temporal_attention(const void* qkv, void* out, int B, int F, int HW, int C, int heads,
+                             float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * hallo_groupnorm_nhwc: per-frame GroupNorm (+ optional SiLU) on [n_img, HW, C].
+ * Replaces InflatedGroupNorm (hallo/models/resnet.py:88-101) + SiLU in ResnetBlock3D
+ * (resnet.py:385-386,396,402), conv_norm_out (unet_3d.py:708-709), Transformer3DModel.norm
+ * (transformer_3d.py:197, eps 1e-6), TemporalTransformer3DModel.norm (motion_module.py:290)
+ * and the AutoencoderKL norms.  workspace: fp32 [n_img * chunks * groups * 2] with
+ * chunks = hallo_groupnorm_chunks(HW).
+ */
+int hallo_groupnorm_chunks(int HW);
+int hallo_groupnorm_nhwc(const void* x, void* y, const void* gamma, const void* beta, float* workspace,
+                         int n_img, int HW, int C, int groups, float eps, int silu, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * hallo_layernorm: row LayerNorm (eps 1e-5 default in torch) with optional positional
+ * encoding add: y[r,:] = LN(x[r,:]) * gamma + beta + pe[(r / pe_rows_per_pos) % pe_len, :].
+ * Replaces nn.LayerNorm at hallo/models/attention.py:563,586,601,812,835,905 and
+ * motion_module.py:408,420, fused with PositionalEncoding.forward (motion_module.py:459-461).
+ * pe is fp32 [pe_len, C] or null.
+ */
+int hallo_layernorm(const void* x, void* y, const void* gamma, const void* beta, const float* pe,
+                    int rows, int C, float eps, int pe_rows_per_pos, int pe_len, int dtype, void* stream);
+
+/* hallo_softmax_rows: y[r,:] = softmax(scale * x[r,:]), x fp32 [rows, cols], y dtype.
+ * Used by the AutoencoderKL mid-block attention (1 head, head_dim 512). */
+int hallo_softmax_rows(const float* x, void* y, int rows, int cols, float scale, int dtype, void* stream);
+
+/* hallo_copy2d: dst[r, 0:width] = src[r, 0:width] for r < rows (element pitches).  Used for the skip
+ * concatenation (unet_3d_blocks.py:1131,1373) and the motion-frame concat (unet_3d_blocks.py:740). */
+int hallo_copy2d(const void* src, int64_t src_pitch, void* dst, int64_t dst_pitch, int64_t rows, int width,
+                 int dtype, void* stream);
+
+/* hallo_nchw_to_nhwc: x [n, C, HW] (fp32 if src_f32 else dtype) -> y [n, HW, Cpad] dtype, channels
+ * >= C zero-filled.  hallo_nhwc_to_nchw_f32: x [n, HW, ldx] dtype -> y fp32 [n, C, HW] with
+ * y = clamp(x*mul + add, lo, hi) (decode_latents post-processing, face_animate.py:243). */
+int hallo_nchw_to_nhwc(const void* x, void* y, int n, int C, int HW, int Cpad, int src_f32, int dtype, void* stream);
+int hallo_nhwc_to_nchw_f32(const void* x, float* y, int n, int C, int HW, int64_t ldx, float mul, float add,
+                           float lo, float hi, int dtype, void* stream);
+
+/* hallo_timestep_embedding: diffusers Timesteps(dim, flip_sin_to_cos=True, shift=0)
+ * (hallo/models/unet_3d.py:184-185,582): out[b, :] = [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(1e4)*i/half). */
+int hallo_timestep_embedding(const float* t, void* out, int batch, int dim, int dtype, void* stream);
+
+/* hallo_cfg_ddim_step: classifier-free guidance combine + DDIM (eta = 0) v-prediction update
+ * (hallo/animate/face_animate.py:415-420; diffusers DDIMScheduler.step):
+ *   v      = guidance ? uncond + gs * (cond - uncond) : model_out
+ *   x0     = sqrt(a_t) * x - sqrt(1 - a_t) * v ; eps = sqrt(a_t) * v + sqrt(1 - a_t) * x
+ *   x_prev = sqrt(a_prev) * x0 + sqrt(1 - a_prev) * eps
+ * model_out: dtype [B*F, HW, ldm] token-major (cond batch follows uncond batch when cfg=1),
+ * latents: fp32 [F, HW, C] token-major, updated in place; next_in: dtype [F, HW, ldn] (the next
+ * UNet input, channels >= C zero) written for both CFG halves by the caller's layout. */
+int hallo_cfg_ddim_step(const void* model_out, int64_t ldm, float* latents, void* next_in, int64_t ldn,
+                        int rows, int C, int cfg, float guidance_scale, float alpha_t, float alpha_prev,
+                        int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HALLO_AMD_H */

@@ -1,0 +1,365 @@
+"""GPU parity tests, operator tier: every HIP kernel (through the C ABI) vs the fp32 oracle
+expression of the same reference op on identical fp16/bf16-rounded inputs.
+
+Tolerances ("Proposed parity tolerances"), stated per storage type:
+    max-abs <= 2^-8 * |ref|_inf (fp16) / 2^-6 * |ref|_inf (bf16)
+    relative L2 <= 2e-3 (fp16) / 1e-2 (bf16)
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def _tol(dtype):
+    return (2.0 ** -8, 2e-3) if dtype == torch.float16 else (2.0 ** -6, 1e-2)
+
+
+def _check(name, got, ref, dtype, report, scale=1.0):
+    got = got.float()
+    ref = ref.float()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    err = (got - ref).abs().max().item()
+    refmax = ref.abs().max().item()
+    rel = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+    ma, rl = _tol(dtype)
+    rec = {"test": name, "dtype": str(dtype), "max_abs_err": err, "ref_absmax": refmax, "rel_l2": rel,
+           "tol_max_abs": ma * refmax * scale, "tol_rel_l2": rl * scale}
+    report.append(rec)
+    print(rec)
+    assert err <= ma * refmax * scale + 1e-6, rec
+    assert rel <= rl * scale, rec
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _rand(shape, dtype, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen, dtype=torch.float32) * scale).to(dtype).to(_dev())
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 320, 320), (1000, 328, 776), (70, 24, 2560), (4096, 1280, 320),
+                                   (2, 1280, 320)])
+def test_gemm_plain(dtype, M, N, K, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = _rand((M, K), dtype, g)
+    w = _rand((N, K), dtype, g, K ** -0.5)
+    bias = _rand((N,), dtype, g)
+    out = ops.gemm(a, w, bias)
+    _check(f"gemm_plain[{M},{N},{K}]", out, ops_ref.linear(a, w, bias), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_asymmetric_layout(dtype, report):
+    """A = identity-like rows, asymmetric W: catches transposed / permuted fragment layouts."""
+    from hallo_amd import ops
+    M = N = K = 128
+    a = torch.eye(M, K, dtype=torch.float32)
+    w = (torch.arange(N)[:, None] * 0.25 + torch.arange(K)[None, :] * 3.0).float() / 512.0
+    a = a.to(dtype).to(_dev())
+    w = w.to(dtype).to(_dev())
+    out = ops.gemm(a, w, None)
+    ref = a.float() @ w.float().t()
+    _check("gemm_identity_asym", out, ref, dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(dtype, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 520, 200, 320
+    a = _rand((M, K), dtype, g)
+    w = _rand((N, K), dtype, g, K ** -0.5)
+    bias = _rand((N,), dtype, g)
+    res = _rand((M, N), dtype, g)
+    rs = torch.rand((M,), generator=g).to(_dev())
+    # rowscale + alpha + residual (audio branch: s_k * zero_conv(mask * attn_out) + hidden)
+    out = ops.gemm(a, w, bias, residual=res, rowscale=rs, alpha=0.75)
+    ref = 0.75 * rs[:, None] * ops_ref.linear(a, w, bias) + res.float()
+    _check("gemm_rowscale_alpha_residual", out, ref, dtype, report)
+    # in-place residual (C aliases residual)
+    res2 = res.clone()
+    ops.gemm(a, w, bias, residual=res2, out=res2)
+    _check("gemm_inplace_residual", res2, ops_ref.linear(a, w, bias) + res.float(), dtype, report)
+    # SiLU epilogue (TimestepEmbedding) and fp32 output
+    out = ops.gemm(a, w, bias, act=ops.ACT_SILU)
+    _check("gemm_silu", out, torch.nn.functional.silu(ops_ref.linear(a, w, bias)), dtype, report)
+    out = ops.gemm(a, w, None, out_f32=True)
+    assert out.dtype == torch.float32
+    _check("gemm_out_f32", out, ops_ref.linear(a, w), dtype, report)
+    # per-group bias2 (time embedding per batch entry): 2 groups of 260 rows
+    b2 = _rand((2, N), dtype, g)
+    out = ops.gemm(a, w, bias, bias2=b2, bias2_rows_per_group=260)
+    ref = ops_ref.linear(a, w, bias) + b2.float().repeat_interleave(260, dim=0)
+    _check("gemm_bias2", out, ref, dtype, report)
+    # per-row bias (V^T projection of the VAE attention)
+    brow = _rand((M,), dtype, g)
+    out = ops.gemm(a, w, brow, bias_per_row=True)
+    _check("gemm_bias_per_row", out, ops_ref.linear(a, w) + brow.float()[:, None], dtype, report)
+    # strided A (column slice of a wider buffer)
+    wide = _rand((M, 3 * K), dtype, g)
+    out = ops.gemm(wide[:, K:2 * K], w, bias)
+    _check("gemm_strided_a", out, ops_ref.linear(wide[:, K:2 * K], w, bias), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Cd", [(300, 320), (1024, 640)])
+def test_gemm_geglu(dtype, M, Cd, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(5 + Cd)
+    a = _rand((M, Cd), dtype, g)
+    w = _rand((8 * Cd, Cd), dtype, g, Cd ** -0.5)
+    bias = _rand((8 * Cd,), dtype, g)
+    out = ops.gemm(a, w, bias, geglu=True)
+    _check(f"gemm_geglu[{M},{Cd}]", out, ops_ref.geglu(a, w, bias), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_batched(dtype, report):
+    from hallo_amd import ops
+    g = torch.Generator().manual_seed(17)
+    Bn, M, N, K = 3, 200, 136, 512
+    a = _rand((Bn, M, K), dtype, g)
+    w = _rand((Bn, N, K), dtype, g, K ** -0.5)
+    out = torch.empty((Bn, M, N), device=_dev(), dtype=torch.float32)
+    ops.gemm_batched(a, w, out, out_f32=True)
+    ref = torch.einsum("bmk,bnk->bmn", a.float(), w.float())
+    _check("gemm_batched_f32", out, ref, dtype, report)
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    dict(n=2, H=16, W=16, Cin=64, Cout=96, stride=1, up=False),
+    dict(n=3, H=12, W=20, Cin=320, Cout=320, stride=1, up=False),
+    dict(n=2, H=16, W=16, Cin=64, Cout=64, stride=2, up=False),
+    dict(n=2, H=8, W=8, Cin=128, Cout=72, stride=1, up=True),
+    dict(n=1, H=24, W=24, Cin=8, Cout=320, stride=1, up=False),     # conv_in (4 -> padded 8 channels)
+    dict(n=1, H=16, W=16, Cin=16, Cout=32, stride=2, up=False),     # FaceLocator widths
+    dict(n=2, H=10, W=10, Cin=1920, Cout=64, stride=1, up=False),   # wide skip-concat input
+])
+def test_conv3x3(dtype, cfg, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(cfg["Cin"] + cfg["Cout"])
+    n, H, W, Cin, Cout = cfg["n"], cfg["H"], cfg["W"], cfg["Cin"], cfg["Cout"]
+    x = _rand((n, H * W, Cin), dtype, g)
+    w = _rand((Cout, Cin, 3, 3), dtype, g, (9 * Cin) ** -0.5)
+    bias = _rand((Cout,), dtype, g)
+    w_nhwc = w.permute(0, 2, 3, 1).contiguous()
+    out = ops.conv3x3(x, w_nhwc, bias, n, H, W, stride=cfg["stride"], upsample=cfg["up"])
+    ref, oh, ow = ops_ref.conv3x3_nhwc(x, w, bias, n, H, W, stride=cfg["stride"], upsample=cfg["up"])
+    assert out.shape[1] == oh * ow
+    _check(f"conv3x3[{cfg}]", out, ref, dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_asym_pad_and_epilogue(dtype, report):
+    """VAE encoder downsample: pad (0,1,0,1) + stride 2; resnet epilogue: temb bias2 + residual."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(23)
+    n, H, W, Cin, Cout = 2, 16, 16, 128, 128
+    x = _rand((n, H * W, Cin), dtype, g)
+    w = _rand((Cout, Cin, 3, 3), dtype, g, (9 * Cin) ** -0.5)
+    bias = _rand((Cout,), dtype, g)
+    w_nhwc = w.permute(0, 2, 3, 1).contiguous()
+    out = ops.conv3x3(x, w_nhwc, bias, n, H, W, stride=2, pad_t=0, pad_l=0, out_hw=(8, 8))
+    ref, oh, ow = ops_ref.conv3x3_nhwc(x, w, bias, n, H, W, stride=2, pad=(0, 1, 0, 1))
+    assert (oh, ow) == (8, 8)
+    _check("conv3x3_asym_pad", out, ref, dtype, report)
+    temb = _rand((n, Cout), dtype, g)
+    res = _rand((n, H * W, Cout), dtype, g)
+    out = ops.conv3x3(x, w_nhwc, bias, n, H, W, bias2=temb, bias2_rows_per_group=H * W, residual=res)
+    ref, _, _ = ops_ref.conv3x3_nhwc(x, w, bias, n, H, W)
+    ref = ref + temb.float()[:, None, :] + res.float()
+    _check("conv3x3_temb_residual", out, ref, dtype, report)
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd,Lq,Lkv", [(40, 256, 256), (40, 200, 100), (80, 128, 64), (80, 300, 333), (160, 64, 64),
+                                       (160, 130, 77), (40, 1024, 1024), (40, 64, 4), (80, 96, 32), (160, 64, 18)])
+def test_attention_single_segment(dtype, hd, Lq, Lkv, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(hd * 1000 + Lq + Lkv)
+    B, H = 2, 8
+    Cd = H * hd
+    q = _rand((B, Lq, Cd), dtype, g)
+    k = _rand((B, Lkv, Cd), dtype, g)
+    v = _rand((B, Lkv, Cd), dtype, g)
+    out = ops.attention(q, k, v, H)
+    _check(f"attn[{hd},{Lq},{Lkv}]", out, ops_ref.sdpa(q, k, v, H), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd,L", [(40, 256), (80, 100), (160, 64)])
+def test_attention_reference_segment_cfg(dtype, hd, L, report):
+    """Fused QKV buffer views + bank K/V shared by the frames of a batch entry, uncond half
+    (first kv2_first_batch rows) attends to self only."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(hd + L)
+    Fr, H = 3, 8
+    Cd = H * hd
+    N = 2 * Fr
+    qkv = _rand((N, L, 3 * Cd), dtype, g)
+    bank_kv = _rand((2, L, 2 * Cd), dtype, g)
+    q, k1, v1 = qkv[:, :, :Cd], qkv[:, :, Cd:2 * Cd], qkv[:, :, 2 * Cd:]
+    k2, v2 = bank_kv[:, :, :Cd], bank_kv[:, :, Cd:]
+    out = ops.attention(q, k1, v1, H, k2=k2, v2=v2, kv2_batch_div=Fr, kv2_first_batch=Fr)
+    ref = ops_ref.reference_self_attention(q, k1, v1, k2, v2, H, Fr, Fr)
+    _check(f"attn_ref_cfg[{hd},{L}]", out, ref, dtype, report)
+    out = ops.attention(q, k1, v1, H, k2=k2, v2=v2, kv2_batch_div=Fr, kv2_first_batch=0)
+    ref = ops_ref.reference_self_attention(q, k1, v1, k2, v2, H, Fr, 0)
+    _check(f"attn_ref_nocfg[{hd},{L}]", out, ref, dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_forced_rescale(dtype, report):
+    """One key far above the rest late in the sequence forces the online-softmax rescale path."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(99)
+    B, H, hd, L = 1, 8, 40, 512
+    Cd = H * hd
+    q = _rand((B, L, Cd), dtype, g)
+    k = _rand((B, L, Cd), dtype, g)
+    v = _rand((B, L, Cd), dtype, g)
+    k[:, 300] = q[:, 7] * 4.0   # spike: row 7 (and correlated rows) jump at kv tile 4
+    k[:, 450] = -q[:, 9] * 4.0
+    out = ops.attention(q, k, v, H)
+    _check("attn_forced_rescale", out, ops_ref.sdpa(q, k, v, H), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cd,HW,Fr,B", [(320, 64, 18, 1), (640, 16, 18, 2), (1280, 4, 18, 1), (320, 9, 10, 2)])
+def test_temporal_attention(dtype, Cd, HW, Fr, B, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(Cd + HW)
+    qkv = _rand((B * Fr, HW, 3 * Cd), dtype, g)
+    out = ops.temporal_attention(qkv, B, Fr, HW, Cd, 8)
+    _check(f"temporal_attn[{Cd},{HW},{Fr},{B}]", out, ops_ref.temporal_attention(qkv, B, Fr, HW, Cd, 8), dtype, report)
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,HW,Cd,silu,eps", [(3, 256, 320, True, 1e-5), (2, 1024, 640, False, 1e-6), (2, 64, 2560, True, 1e-5),
+                                              (1, 4096, 128, True, 1e-6), (2, 100, 960, False, 1e-5), (1, 70000, 128, True, 1e-6)])
+def test_groupnorm(dtype, n, HW, Cd, silu, eps, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(n + HW + Cd)
+    x = (_rand((n, HW, Cd), dtype, g).float() * 2.0 + 1.5).to(dtype)   # non-zero mean
+    gamma = _rand((Cd,), dtype, g)
+    beta = _rand((Cd,), dtype, g)
+    out = ops.groupnorm(x, gamma, beta, n, HW, 32, eps, silu=silu)
+    _check(f"groupnorm[{n},{HW},{Cd},{silu}]", out, ops_ref.groupnorm_nhwc(x, gamma, beta, 32, eps, silu), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,Cd", [(1000, 320), (333, 640), (64, 1280), (50, 768)])
+def test_layernorm(dtype, rows, Cd, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(rows + Cd)
+    x = (_rand((rows, Cd), dtype, g).float() * 3.0 + 0.5).to(dtype)
+    gamma = _rand((Cd,), dtype, g)
+    beta = _rand((Cd,), dtype, g)
+    out = ops.layernorm(x, gamma, beta)
+    _check(f"layernorm[{rows},{Cd}]", out, ops_ref.layernorm(x, gamma, beta), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_with_pe(dtype, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(3)
+    B, Fr, HW, Cd = 2, 6, 10, 320
+    x = _rand((B * Fr, HW, Cd), dtype, g)
+    gamma = _rand((Cd,), dtype, g)
+    beta = _rand((Cd,), dtype, g)
+    pe = torch.randn((32, Cd), generator=g).to(dtype).float().to(_dev())
+    out = ops.layernorm(x, gamma, beta, pe=pe[:Fr].contiguous(), pe_rows_per_pos=HW, pe_len=Fr)
+    ref = ops_ref.layernorm(x, gamma, beta, pe=pe[:Fr], pe_rows_per_pos=HW)
+    _check("layernorm_pe", out, ref, dtype, report, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_rows(dtype, report):
+    from hallo_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn((37, 4096), generator=g) * 4.0).to(_dev())
+    out = torch.empty((37, 4096), device=_dev(), dtype=dtype)
+    ops.softmax_rows(x, out, 0.3)
+    _check("softmax_rows", out, torch.softmax(x * 0.3, dim=-1), dtype, report)
+
+
+def test_layout_and_copy(report):
+    from hallo_amd import ops
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn((3, 4, 100), generator=g).to(_dev())
+    y = ops.nchw_to_nhwc(x, 3, 4, 100, 8, dtype)
+    ref = torch.zeros((3, 100, 8))
+    ref[:, :, :4] = x.cpu().permute(0, 2, 1)
+    _check("nchw_to_nhwc", y, ref.to(dtype).to(_dev()), dtype, report)
+    back = ops.nhwc_to_nchw_f32(y, 3, 4, 100, mul=0.5, add=0.5, lo=0.0, hi=1.0)
+    refb = (x.to(dtype).float() * 0.5 + 0.5).clamp(0, 1)
+    _check("nhwc_to_nchw_f32", back, refb, dtype, report)
+    # concat two channel blocks with copy2d
+    a = _rand((50, 64), dtype, g)
+    b = _rand((50, 192), dtype, g)
+    cat = torch.empty((50, 256), device=_dev(), dtype=dtype)
+    ops.copy2d(a, cat[:, :64], 50, 64)
+    ops.copy2d(b, cat[:, 64:], 50, 192)
+    assert torch.equal(cat, torch.cat([a, b], dim=1))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_timestep_embedding(dtype, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    t = torch.tensor([999.0, 959.0, 39.0, 0.0], device=_dev())
+    out = ops.timestep_embedding(t, 320, dtype)
+    _check("timestep_embedding", out, ops_ref.timestep_embedding(t, 320), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [False, True])
+def test_cfg_ddim_step(dtype, cfg, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(12)
+    rows, Cd = 4 * 64, 4
+    lat = torch.randn((rows, Cd), generator=g).to(_dev())
+    mo = _rand(((2 if cfg else 1) * rows, 8), dtype, g)
+    nxt = torch.zeros(((2 if cfg else 1) * rows, 8), device=_dev(), dtype=dtype)
+    a_t, a_p = 0.1415126324, 0.3
+    lat0 = lat.clone()
+    ops.cfg_ddim_step(mo, lat, nxt, rows, Cd, cfg, 3.5, a_t, a_p)
+    m = mo.float()[:, :Cd]
+    v = m[:rows] + 3.5 * (m[rows:] - m[:rows]) if cfg else m
+    ref = ops_ref.ddim_v_step(lat0, v, a_t, a_p)
+    got = lat
+    err = (got - ref).abs().max().item()
+    report.append({"test": f"cfg_ddim[{cfg}]", "dtype": str(dtype), "max_abs_err": err})
+    assert err < 1e-5, err
+    assert torch.equal(nxt[:rows, :Cd], lat.to(dtype))
+    if cfg:
+        assert torch.equal(nxt[rows:, :Cd], lat.to(dtype))
