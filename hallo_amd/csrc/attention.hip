@@ -28,7 +28,7 @@ struct AttnArgs {
   const void* q; const void* k1; const void* v1; const void* k2; const void* v2; void* o;
   int batch, heads, Lq, Lkv1, Lkv2;
   long q_bs, q_rs, k1_bs, k1_rs, v1_bs, v1_rs, k2_bs, k2_rs, v2_bs, v2_rs, o_bs, o_rs;
-  int kv2_div, kv2_first;
+  int kv2_div, kv2_mod, kv2_first;
   float scale_log2e;
   int nqb;  // query blocks per (batch, head)
 };
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   const T* __restrict__ K1 = reinterpret_cast<const T*>(p.k1) + (long)b * p.k1_bs + h * HD;
   const T* __restrict__ V1 = reinterpret_cast<const T*>(p.v1) + (long)b * p.v1_bs + h * HD;
   const bool use2 = p.k2 != nullptr && p.Lkv2 > 0 && b >= p.kv2_first;
-  const int b2 = use2 ? b / p.kv2_div : 0;
+  const int b2 = use2 ? (p.kv2_mod > 0 ? (b / p.kv2_div) % p.kv2_mod : b / p.kv2_div) : 0;
   const T* __restrict__ K2 = use2 ? reinterpret_cast<const T*>(p.k2) + (long)b2 * p.k2_bs + h * HD : K1;
   const T* __restrict__ V2 = use2 ? reinterpret_cast<const T*>(p.v2) + (long)b2 * p.v2_bs + h * HD : V1;
   T* __restrict__ Og = reinterpret_cast<T*>(p.o) + (long)b * p.o_bs + h * HD;
@@ -371,6 +371,7 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
   a.v2_bs = d->v2_bs; a.v2_rs = d->v2_rs; a.o_bs = d->o_bs; a.o_rs = d->o_rs;
   a.kv2_div = d->kv2_batch_div > 0 ? d->kv2_batch_div : 1;
   a.kv2_first = d->kv2_first_batch;
+  a.kv2_mod = d->kv2_batch_mod;
   a.scale_log2e = d->scale * 1.4426950408889634f;
   a.nqb = (d->Lq + 127) / 128;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

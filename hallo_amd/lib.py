@@ -66,7 +66,7 @@ class AttnDesc(C.Structure):
         ("q_bs", C.c_int64), ("q_rs", C.c_int64), ("k1_bs", C.c_int64), ("k1_rs", C.c_int64),
         ("v1_bs", C.c_int64), ("v1_rs", C.c_int64), ("k2_bs", C.c_int64), ("k2_rs", C.c_int64),
         ("v2_bs", C.c_int64), ("v2_rs", C.c_int64), ("o_bs", C.c_int64), ("o_rs", C.c_int64),
-        ("kv2_batch_div", C.c_int), ("kv2_first_batch", C.c_int),
+        ("kv2_batch_div", C.c_int), ("kv2_batch_mod", C.c_int), ("kv2_first_batch", C.c_int),
         ("scale", C.c_float),
         ("dtype", C.c_int),
     ]

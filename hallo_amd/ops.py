@@ -126,7 +126,8 @@ def conv3x3(x, w, bias, n_img, H, W, *, stride=1, pad_t=1, pad_l=1, out_hw=None,
     return out
 
 
-def attention(q, k1, v1, heads, *, k2=None, v2=None, kv2_batch_div=1, kv2_first_batch=0, out=None, scale=None):
+def attention(q, k1, v1, heads, *, k2=None, v2=None, kv2_batch_div=1, kv2_batch_mod=0, kv2_first_batch=0, out=None,
+              scale=None):
     """softmax(q k^T * scale) v over up to two key/value segments.
 
     q [B, Lq, C], k1/v1 [B, Lkv1, C], k2/v2 [B2, Lkv2, C] are views with contiguous last dim
@@ -154,7 +155,7 @@ def attention(q, k1, v1, heads, *, k2=None, v2=None, kv2_batch_div=1, kv2_first_
     else:
         d.k2_bs = d.k2_rs = d.v2_bs = d.v2_rs = 0
     d.o_bs, d.o_rs = out.stride(0), out.stride(1)
-    d.kv2_batch_div, d.kv2_first_batch = kv2_batch_div, kv2_first_batch
+    d.kv2_batch_div, d.kv2_batch_mod, d.kv2_first_batch = kv2_batch_div, kv2_batch_mod, kv2_first_batch
     d.scale = float(scale if scale is not None else hd ** -0.5)
     d.dtype = dtype_code(q.dtype)
     _l.check(_l.load().hallo_attention(C.byref(d), _stream()), "hallo_attention")

@@ -101,7 +101,9 @@ int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream);
  *   - the reference-augmented spatial self-attention (K/V = [self ; ReferenceNet bank],
  *     hallo/models/mutual_self_attention.py:253-263) including the CFG rule that the
  *     unconditional batch entries attend to themselves only (:264-284): segment 2 is skipped
- *     for batch index < kv2_first_batch;
+ *     for batch index < kv2_first_batch; the bank entry of batch row b is (b / kv2_batch_div) %
+ *     kv2_batch_mod, which covers the reference's tiled frame->bank mapping (:235-247, bank row
+ *     n % 2 under CFG) as div=1, mod=2;
  *   - the audio block's spatial self-attention (hallo/models/attention.py:828-831);
  *   - the face-token cross-attention (mutual_self_attention.py:296-303) and the three
  *     hierarchical audio cross-attentions (attention.py:846-884) with Lkv = 4 / 32.
@@ -113,7 +115,8 @@ typedef struct hallo_attn_desc {
   const void* q; const void* k1; const void* v1; const void* k2; const void* v2; void* o;
   int batch, heads, head_dim, Lq, Lkv1, Lkv2;
   int64_t q_bs, q_rs, k1_bs, k1_rs, v1_bs, v1_rs, k2_bs, k2_rs, v2_bs, v2_rs, o_bs, o_rs;
-  int kv2_batch_div;    /* segment-2 batch index = b / kv2_batch_div (frames share one bank) */
+  int kv2_batch_div;    /* segment-2 batch index = (b / kv2_batch_div) % kv2_batch_mod */
+  int kv2_batch_mod;    /* <= 0: no modulo */
   int kv2_first_batch;  /* batches below this index skip segment 2 (CFG uncond half) */
   float scale;          /* head_dim^-0.5 */
   int dtype;

@@ -55,13 +55,15 @@ def sdpa(q, k, v, heads, scale=None):
     return (p @ vh).transpose(1, 2).reshape(B, Lq, C)
 
 
-def reference_self_attention(q, k1, v1, k2, v2, heads, kv2_batch_div, kv2_first_batch):
+def reference_self_attention(q, k1, v1, k2, v2, heads, kv2_batch_div, kv2_first_batch, kv2_batch_mod=0):
     """Net semantics of hallo/models/mutual_self_attention.py:253-284: batch rows
     >= kv2_first_batch attend to cat[self, bank], rows below attend to self only."""
     outs = []
     for b in range(q.shape[0]):
         if k2 is not None and b >= kv2_first_batch:
             b2 = b // kv2_batch_div
+            if kv2_batch_mod > 0:
+                b2 %= kv2_batch_mod
             kk = torch.cat([k1[b], k2[b2]], dim=0)[None]
             vv = torch.cat([v1[b], v2[b2]], dim=0)[None]
         else:

@@ -227,6 +227,10 @@ def test_attention_reference_segment_cfg(dtype, hd, L, report):
     out = ops.attention(q, k1, v1, H, k2=k2, v2=v2, kv2_batch_div=Fr, kv2_first_batch=0)
     ref = ops_ref.reference_self_attention(q, k1, v1, k2, v2, H, Fr, 0)
     _check(f"attn_ref_nocfg[{hd},{L}]", out, ref, dtype, report)
+    # the reference's tiled frame -> bank mapping under CFG: bank row = n % 2
+    out = ops.attention(q, k1, v1, H, k2=k2, v2=v2, kv2_batch_div=1, kv2_batch_mod=2, kv2_first_batch=Fr)
+    ref = ops_ref.reference_self_attention(q, k1, v1, k2, v2, H, 1, Fr, kv2_batch_mod=2)
+    _check(f"attn_ref_tiled[{hd},{L}]", out, ref, dtype, report)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
