@@ -1,0 +1,325 @@
+#!/usr/bin/env python
+"""bench.py -- generated frames/sec of the Hallo denoising hot path on MI355X.
+
+Metric (BASELINE.json): generated frames/sec at 512x512, 16-frame window, 25 DDIM steps.
+Workload at every N (weak scaling): BASELINE config #2 per GPU -- one clip = FaceAnimatePipeline.__call__
+on synthetic inputs already resident in HBM: face tokens + VAE-encode(3) + FaceLocator + ReferenceNet write
++ 25 x (UNet3D, B=1, no CFG) + fused DDIM + batched VAE decode(16) + D2H of the fp32 frames; for N > 1 one
+RCCL all-gather of the decoded frames per wave of clips (BASELINE config #4's exchange).
+A "step" = one clip per rank.  bf16 storage, fp32 accumulation, random-init weights of the reference
+architecture, synthetic inputs.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Extra objects on the JSON line: `roofline` (dominant kernel family, measured with events on the launch
+stream in an instrumented extra clip), `cpu_baseline` (the CPU oracle timed on this box's host cores,
+rank 0 at N = 1), `kernels` (per-family time / achieved rate of the instrumented clip).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16/fp16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+# ------------------------------------------------------------------------------------------------
+# instrumentation: time every operator launch with events on the launch stream, by kernel family
+# ------------------------------------------------------------------------------------------------
+class OpProfiler:
+    def __init__(self):
+        self.records = []
+        self._orig = {}
+
+    def _wrap(self, name, fn, cost):
+        def w(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a, **k)
+            e.record()
+            fl, by = cost(a, k, r)
+            self.records.append((name, s, e, fl, by))
+            return r
+        return w
+
+    def install(self):
+        from hallo_amd import ops
+        es = 2  # bytes per element (fp16 / bf16)
+
+        def c_gemm(a, k, r):
+            M, K = a[0].shape
+            N = r.shape[1]
+            mult = 2 if k.get("geglu") else 1
+            return 2.0 * M * N * K * mult, es * (M * K + N * K * mult + M * N * (2 if k.get("residual") is not None else 1))
+
+        def c_gemmb(a, k, r):
+            B, M, K = a[0].shape
+            N = a[1].shape[1]
+            return 2.0 * B * M * N * K, es * B * (M * K + N * K) + r.element_size() * B * M * N
+
+        def c_conv(a, k, r):
+            n, L, Co = r.shape
+            Ci = a[0].shape[-1]
+            return 2.0 * n * L * Co * 9 * Ci, es * (a[0].numel() + a[1].numel() + r.numel() * (2 if k.get("residual") is not None else 1))
+
+        def c_attn(a, k, r):
+            q, k1 = a[0], a[1]
+            B, Lq, Cq = q.shape
+            L1 = k1.shape[1]
+            k2 = k.get("k2")
+            L2 = k2.shape[1] if k2 is not None else 0
+            nb2 = B - k.get("kv2_first_batch", 0) if k2 is not None else 0
+            fl = 4.0 * Cq * Lq * (B * L1 + nb2 * L2)
+            by = es * Cq * (2 * B * Lq + 2 * B * L1 + 2 * (k2.shape[0] * L2 if k2 is not None else 0))
+            return fl, by
+
+        def c_tattn(a, k, r):
+            qkv = a[0]
+            B, F, HW, Cd = a[1], a[2], a[3], a[4]
+            return 4.0 * B * HW * F * F * Cd, es * (qkv.numel() + r.numel())
+
+        def c_gn(a, k, r):
+            return 8.0 * a[0].numel(), es * 3 * a[0].numel()      # stats pass + apply pass read, one write
+
+        def c_ln(a, k, r):
+            return 8.0 * a[0].numel(), es * 2 * a[0].numel()
+
+        def c_copy(a, k, r):
+            return 0.0, es * 2 * a[2] * a[3]
+
+        def c_sm(a, k, r):
+            return 4.0 * a[0].numel(), 4 * a[0].numel() + es * a[1].numel()
+
+        def c_small(a, k, r):
+            return 0.0, 0.0
+
+        table = dict(gemm=c_gemm, gemm_batched=c_gemmb, conv3x3=c_conv, attention=c_attn, temporal_attention=c_tattn,
+                     groupnorm=c_gn, layernorm=c_ln, copy2d=c_copy, softmax_rows=c_sm, nchw_to_nhwc=c_small,
+                     nhwc_to_nchw_f32=c_small, timestep_embedding=c_small, cfg_ddim_step=c_small)
+        for name, cost in table.items():
+            self._orig[name] = getattr(ops, name)
+            setattr(ops, name, self._wrap(name, self._orig[name], cost))
+
+    def remove(self):
+        from hallo_amd import ops
+        for name, fn in self._orig.items():
+            setattr(ops, name, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        fam = {}
+        for name, s, e, fl, by in self.records:
+            d = fam.setdefault(name, dict(ms=0.0, flop=0.0, bytes=0.0, launches=0))
+            d["ms"] += s.elapsed_time(e)
+            d["flop"] += fl
+            d["bytes"] += by
+            d["launches"] += 1
+        for d in fam.values():
+            d["tflops"] = d["flop"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+            d["gbs"] = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+        return fam
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (plain PyTorch restatement of the reference) on this box's host cores
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(frames, steps_ddim, budget_s=30.0):
+    from oracle import hallo_ref as H
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    with torch.device("meta"):
+        den = H.UNet3DConditionModel()
+        ref = H.UNet2DConditionModel()
+    chunk = torch.randn(1 << 22) * 0.02
+
+    def fill(m):
+        m.to_empty(device="cpu")
+        with torch.no_grad():
+            for name, p in list(m.named_parameters()) + list(m.named_buffers()):
+                flat = p.view(-1)
+                if "norm" in name and name.endswith("weight") and p.dim() == 1:
+                    flat.fill_(1.0)
+                    continue
+                for o in range(0, flat.numel(), chunk.numel()):
+                    n = min(chunk.numel(), flat.numel() - o)
+                    flat[o:o + n] = chunk[:n]
+        return m.eval()
+    den, ref = fill(den), fill(ref)
+    # PE buffers were overwritten by fill(); irrelevant for timing
+    build_s = time.time() - t0
+
+    def unet_time(S, Fr):
+        h = S // 8
+        g = torch.Generator().manual_seed(0)
+        lat = torch.randn((1, 4, Fr, h, h), generator=g)
+        enc = torch.randn((1, 4, 768), generator=g)
+        audio = torch.randn((1, Fr, 32, 768), generator=g)
+        fm = torch.randn((1, 320, Fr, h, h), generator=g)
+        mk = lambda: [torch.rand((Fr, (h // 2 ** l) ** 2), generator=g) for l in range(4)]
+        with torch.no_grad():
+            t = time.time()
+            banks = [b.to(torch.float16) for b in ref(torch.randn((3, 4, h, h), generator=g), torch.tensor(0), enc)]
+            t_ref = time.time() - t
+            t = time.time()
+            den(lat, torch.tensor(500), enc, banks, audio_embedding=audio, mask_cond_fea=fm, full_mask=mk(),
+                face_mask=mk(), lip_mask=mk(), motion_scale=[1.0, 1.0, 1.0])
+            return time.time() - t, t_ref
+    # TFLOP per UNet3D forward: 2.74 @256^2 x 8f, 25.59 @512^2 x 16f (B = 1)
+    t_small, _ = unet_time(256, 8)
+    if t_small * (25.59 / 2.74) <= budget_s:
+        t_unet, t_ref = unet_time(512, 16)
+        sample = "1 UNet3D forward + ReferenceNet write at 512x512x16f (B=1, fp32), measured"
+    else:
+        t_unet, t_ref = t_small * (25.59 / 2.74), None
+        sample = ("1 UNet3D forward at 256x256x8f (B=1, fp32) = %.1f s, scaled by the FLOP ratio 25.59/2.74 to "
+                  "512x512x16f" % t_small)
+    rate = 25.59 / t_unet                                   # achieved CPU TFLOP/s on the UNet
+    other = (frames * 2.515 + 3 * 1.117 + 2.4) / rate        # VAE decode/encode + ReferenceNet by FLOP ratio
+    clip_s = steps_ddim * t_unet + other
+    return {"value": frames / clip_s, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": sample + "; clip = %d x that + VAE/ReferenceNet by FLOP ratio (extrapolated); oracle build %.0f s"
+            % (steps_ddim, build_s), "unet_forward_s": t_unet}
+
+
+# ------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed clips per rank")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--ddim-steps", type=int, default=25)
+    ap.add_argument("--guidance", type=float, default=1.0, help="1.0 = BASELINE config #2 (no CFG); 3.5 = config #3")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    from hallo_amd import lib
+    lib.load()
+    from hallo_amd.synthetic import build_pipeline, clip_inputs
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    pipe, audioproj = build_pipeline(dev, dtype)
+    S, Fr = args.size, args.frames
+    gathered = torch.empty((world, Fr, 3, S * S), device=dev, dtype=torch.float32) if world > 1 else None
+    host = torch.empty((Fr, 3, S * S), dtype=torch.float32).pin_memory()
+
+    def one_clip(idx):
+        d = clip_inputs(S, Fr, seed=1234 + rank * 1000 + idx, device=dev)
+        torch.cuda.synchronize()
+        return d
+
+    def run(d):
+        audio = audioproj(d["audio_emb"])
+        lat = pipe(d["ref_image"], d["face_emb"], audio, d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr,
+                   args.ddim_steps, args.guidance, motion_scale=d["motion_scale"], latents=d["latents"], decode=False)
+        h = S // 8
+        lat = lat[0].permute(1, 2, 3, 0).reshape(Fr * h * h, 4).contiguous()
+        frames, _, _ = pipe.decode_latents_device(lat, Fr, h, h)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, frames)      # decoded frames of all clips, clip order = rank
+            if rank == 0:
+                host.copy_(gathered[0], non_blocking=True)
+        else:
+            host.copy_(frames, non_blocking=True)
+        return frames
+
+    inputs = [one_clip(i) for i in range(args.warmup + args.steps)]
+    for i in range(args.warmup):
+        run(inputs[i])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run(inputs[args.warmup + i])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_frames = world * args.steps * Fr
+    out = {
+        "metric": "generated frames/sec at 512x512, 16-frame window, 25 DDIM steps",
+        "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic (random-init weights of the reference architecture, synthetic clip inputs)",
+        "config": {"workload": f"BASELINE config #2 per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
+                               f"steps, guidance {args.guidance} ({'CFG, B=2' if args.guidance > 1 else 'no CFG, B=1'}), "
+                               "ReferenceNet + VAE encode/decode + D2H inside the timed region",
+                   "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (" + RCCL all-gather of frames" if world > 1 else "")},
+    }
+
+    if rank == 0 and not args.no_profile:
+        prof = OpProfiler()
+        prof.install()
+        run(inputs[-1])
+        fam = prof.summary()
+        prof.remove()
+        tot_ms = sum(d["ms"] for d in fam.values())
+        tot_flop = sum(d["flop"] for d in fam.values())
+        out["kernels"] = {k: {"ms": round(d["ms"], 2), "launches": d["launches"], "tflops": round(d["tflops"], 1),
+                              "gbs": round(d["gbs"], 1)} for k, d in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+        out["kernel_ms_per_clip"] = round(tot_ms, 1)
+        out["algorithmic_tflop_per_clip"] = round(tot_flop / 1e12, 1)
+        dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        name, d = dom
+        if name in ("gemm", "conv3x3", "attention", "gemm_batched"):
+            out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(d["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_clip": d["launches"]}
+        else:
+            out["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(d["gbs"], 1), "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": round(d["gbs"] / PEAK_HBM_GBS, 4), "traffic": None,
+                               "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_clip": d["launches"]}
+        if "attention" in fam:
+            a = fam["attention"]
+            out["attention"] = {"hbm_gbs": round(a["gbs"], 1), "hbm_frac": round(a["gbs"] / PEAK_HBM_GBS, 4),
+                                "tflops": round(a["tflops"], 1), "mfma_frac": round(a["tflops"] / PEAK_BF16_TFLOPS, 4)}
+        out["end_to_end_mfma_frac"] = round(tot_flop / 1e12 / (elapsed / args.steps) / PEAK_BF16_TFLOPS, 4)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(Fr, args.ddim_steps)
+            out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        except Exception as e:  # the baseline is a reported extra; never lose the GPU number to it
+            out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {type(e).__name__}: {e}"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+"""FaceAnimatePipeline -- one sliding-window clip of audio-driven portrait animation on one MI355X.
+
+Reference: hallo/animate/face_animate.py:58-442 (`__call__` 249-442, `prepare_latents` 136-188,
+`decode_latents` 222-246).  Constructor, `to`, `__call__` signature, callback protocol and the output
+(`FaceAnimatePipelineOutput.videos`: fp32 CPU tensor (1, 3, F, H, W) in [0, 1]) are the reference's.
+
+Execution plan (not the reference's):
+  * one-off per clip: face tokens, VAE-encode(3 images), FaceLocator on ONE mask frame (the F frames
+    are identical copies, face_animate.py:339-341), ReferenceNet write pass, reference/face/audio
+    K/V projections (ClipCache);
+  * per DDIM step: one UNet evaluation (batch 2 under CFG) on token-major activations, then ONE fused
+    kernel for CFG combine + DDIM update on fp32 latents that also writes the next UNet input;
+    timestep / alpha lookups are host integers, so there is no device sync inside the loop
+    (the reference syncs twice per step: CPU `alphas_cumprod[t]` with a device `t`, and the CPU `uc_mask`);
+  * decode: all F frames as one batch, clamp + NCHW fp32 conversion fused, one D2H copy.
+
+Deviation from the reference, on purpose: `guidance_scale <= 1` works (the reference doubles the audio
+tensor unconditionally, face_animate.py:377-379, and then dies in the audio cross-attention -- SURVEY F5);
+here nothing is doubled without CFG.  BASELINE config #2 (25 steps, no CFG) needs this.
+"""
+from dataclasses import dataclass
+
+import torch
+
+from .. import ops
+from ..models.attention import ClipCache
+from ..models.mutual_self_attention import ReferenceAttentionControl
+from ..models.unet_3d import pack_masks
+
+
+@dataclass
+class FaceAnimatePipelineOutput:
+    videos: torch.Tensor
+
+
+class FaceAnimatePipeline:
+    def __init__(self, vae, reference_unet, denoising_unet, face_locator, image_proj, scheduler):
+        self.vae, self.reference_unet, self.denoising_unet = vae, reference_unet, denoising_unet
+        self.face_locator, self.image_proj, self.scheduler = face_locator, image_proj, scheduler
+        self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
+        self.timings = {}
+
+    def to(self, device=None, dtype=None):
+        for m in (self.vae, self.reference_unet, self.denoising_unet, self.face_locator, self.image_proj):
+            m.to(device=device, dtype=dtype)
+            m.prepare()
+        return self
+
+    @property
+    def device(self):
+        return self.denoising_unet.device
+
+    def progress_bar(self, iterable=None, total=None):
+        return iterable if iterable is not None else range(total)
+
+    # ------------------------------------------------------------------------------------------
+    def prepare_latents(self, batch_size, num_channels_latents, width, height, video_length, dtype, device, generator,
+                        latents=None):
+        """face_animate.py:136-188 via diffusers randn_tensor: a CPU generator samples on the CPU in the
+        weight dtype, then the tensor moves to the device; scaled by init_noise_sigma (= 1)."""
+        shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor,
+                 width // self.vae_scale_factor)
+        if latents is None:
+            gdev = generator.device if generator is not None else torch.device("cpu")
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype)
+        return latents.to(device) * self.scheduler.init_noise_sigma
+
+    def _image_tokens(self, img, dtype):
+        """(n, 3, H, W) any float dtype -> token-major [n, H*W, 8]"""
+        n, Cin, H, W = img.shape
+        x = img.to(self.device).float().reshape(n, Cin, H * W).contiguous()
+        return ops.nchw_to_nhwc(x, n, Cin, H * W, 8, dtype)
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, ref_image, face_emb, audio_tensor, face_mask, pixel_values_full_mask, pixel_values_face_mask,
+                 pixel_values_lip_mask, width, height, video_length, num_inference_steps, guidance_scale,
+                 num_images_per_prompt=1, eta=0.0, motion_scale=None, generator=None, output_type="tensor",
+                 return_dict=True, callback=None, callback_steps=1, latents=None, decode=True, **kwargs):
+        if eta != 0.0:
+            raise ValueError("the Hallo path runs DDIM with eta = 0 (face_animate.py:420)")
+        dev = self.device
+        dt = self.denoising_unet.dtype
+        den, refnet = self.denoising_unet, self.reference_unet
+        do_cfg = guidance_scale > 1.0
+        B = 2 if do_cfg else 1
+        Fr = video_length
+        h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
+        L = h * w
+        self.scheduler.set_timesteps(num_inference_steps)
+        timesteps = self.scheduler.timesteps
+
+        # -- face tokens (face_animate.py:291-298)
+        cond = self.image_proj(face_emb)
+        if do_cfg:
+            enc = torch.cat([self.image_proj(torch.zeros_like(face_emb)), cond], dim=0)
+        else:
+            enc = cond
+
+        writer = ReferenceAttentionControl(refnet, do_classifier_free_guidance=do_cfg, mode="write", batch_size=1,
+                                           fusion_blocks="full")
+        reader = ReferenceAttentionControl(den, do_classifier_free_guidance=do_cfg, mode="read", batch_size=1,
+                                           fusion_blocks="full")
+
+        # -- latents: fp32 token-major state [F*L, C] + the UNet input buffer [B*F, L, 8]
+        C_lat = den.in_channels
+        lat5 = self.prepare_latents(1, C_lat, width, height, Fr, dt, dev, generator, latents)
+        lat = lat5[0].permute(1, 2, 3, 0).reshape(Fr * L, C_lat).float().contiguous()
+        x_in = torch.zeros((B * Fr, L, 8), device=dev, dtype=dt)
+        x_in.view(B, Fr * L, 8)[:, :, :C_lat] = lat.to(dt)
+
+        # -- reference + motion frames -> latents (face_animate.py:332-336)
+        imgs = ref_image.reshape(-1, *ref_image.shape[2:]) if ref_image.dim() == 5 else ref_image
+        n_ref = imgs.shape[0]
+        ref_lat, _, _ = self.vae.encode_tokens(self._image_tokens(imgs, dt), n_ref, height, width, scale=0.18215)
+
+        # -- face locator on one frame, broadcast over the F identical frames (face_animate.py:339-343)
+        fm = self._image_tokens(face_mask.reshape(-1, *face_mask.shape[-3:])[:1], dt)
+        fea, _, _ = self.face_locator.forward_tokens(fm, 1, height, width)          # [1, L, C0]
+        C0 = fea.shape[-1]
+        mask_cond = torch.zeros((B, Fr, L, C0), device=dev, dtype=dt)
+        mask_cond[B - 1] = fea[0]                                                   # uncond half stays zero
+        mask_cond = mask_cond.view(B * Fr, L, C0)
+
+        # -- masks (face_animate.py:345-374) and audio tokens (:377-379)
+        rep = (lambda ms: [torch.cat([m] * 2) for m in ms]) if do_cfg else (lambda ms: list(ms))
+        masks = pack_masks(rep(pixel_values_full_mask), rep(pixel_values_face_mask), rep(pixel_values_lip_mask), dev, dt)
+        audio = audio_tensor.to(dev, dt)
+        if do_cfg:
+            audio = torch.cat([torch.zeros_like(audio), audio], dim=0)
+        audio = audio.reshape(B * Fr, audio.shape[-2], audio.shape[-1]).contiguous()
+
+        cache = ClipCache()
+        for i, t in enumerate(self.progress_bar(timesteps)):
+            if i == 0:
+                # ReferenceNet write pass on [ref, m1, m2] (x2 under CFG) at t = 0 (face_animate.py:386-395)
+                refnet.written_banks = refnet.forward_tokens(ref_lat.repeat(B, 1, 1), 0, enc, h, w)
+                reader.update(writer)
+            v = den.forward_tokens(x_in, int(t), enc, den.reference_bank, audio, mask_cond, masks, motion_scale, B, Fr,
+                                   h, w, do_cfg, cache)
+            a_t, a_p = self.scheduler.step_alphas(t)
+            ops.cfg_ddim_step(v, lat, x_in, Fr * L, C_lat, do_cfg, guidance_scale, a_t, a_p)
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, lat.view(Fr, h, w, C_lat).permute(3, 0, 1, 2).unsqueeze(0).to(dt))
+        reader.clear()
+        writer.clear()
+        cache.clear()
+        if not decode:
+            return lat.view(Fr, h, w, C_lat).permute(3, 0, 1, 2).unsqueeze(0)
+        video = self.decode_latents(lat, Fr, h, w)
+        if not return_dict:
+            return video
+        return FaceAnimatePipelineOutput(videos=video)
+
+    # ------------------------------------------------------------------------------------------
+    def decode_latents_device(self, lat, frames, h, w):
+        """fp32 token-major latents [F*L, C] -> fp32 device tensor [F, 3, H*W] in [0, 1]."""
+        dt = self.denoising_unet.dtype
+        C_lat = lat.shape[-1]
+        z = torch.zeros((frames, h * w, 8), device=lat.device, dtype=dt)
+        z[:, :, :C_lat] = (lat.view(frames, h * w, C_lat) * (1.0 / 0.18215)).to(dt)
+        img, H, W = self.vae.decode_tokens(z, frames, h, w)
+        # (x / 2 + 0.5).clamp(0, 1) fused with the token-major -> planar fp32 conversion (face_animate.py:243)
+        return ops.nhwc_to_nchw_f32(img, frames, img.shape[-1], H * W, mul=0.5, add=0.5, lo=0.0, hi=1.0), H, W
+
+    def decode_latents(self, lat, frames, h, w):
+        """face_animate.py:222-246 -> (1, 3, F, H, W) fp32 on the CPU."""
+        v, H, W = self.decode_latents_device(lat, frames, h, w)
+        v = v.view(frames, -1, H, W).cpu()
+        return v.permute(1, 0, 2, 3).unsqueeze(0)

@@ -35,6 +35,7 @@ struct GemmArgs {
   int bias_per_row;
   const void* bias2;        // [M/bias2_rpg, N] or null
   int bias2_rpg;
+  long bias2_ld;
   const float* rowscale;    // [M] fp32 or null
   const void* residual;     // [M,N] (ld = ldr) or null
   long ldr, sR;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         if (m >= p.M) continue;
         float v = acc[tm][tn][r] + bcol;
         if (bias && p.bias_per_row) v += to_f32(bias[m]);
-        if (bias2) v += to_f32(bias2[(long)(m / p.bias2_rpg) * p.N + n]);
+        if (bias2) v += to_f32(bias2[(long)(m / p.bias2_rpg) * p.bias2_ld + n]);
         if (p.rowscale) v *= p.rowscale[m];
         v *= p.alpha;
         if (res) v += to_f32(res[(long)m * p.ldr + n]);
@@ -268,6 +269,7 @@ extern "C" int hallo_gemm(const hallo_gemm_desc* d, void* stream) {
   a.sA = d->stride_a; a.sB = d->stride_b; a.sC = d->stride_c;
   a.bias = d->bias; a.bias_per_row = d->bias_per_row;
   a.bias2 = d->bias2; a.bias2_rpg = d->bias2_rows_per_group > 0 ? d->bias2_rows_per_group : 1;
+  a.bias2_ld = d->bias2_ld > 0 ? d->bias2_ld : d->N;
   a.rowscale = d->rowscale;
   a.residual = d->residual; a.ldr = d->ldr; a.sR = d->stride_r;
   a.alpha = d->alpha; a.act = d->act; a.out_f32 = d->out_f32;
@@ -292,6 +294,7 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
   a.sA = a.sB = a.sC = 0;
   a.bias = d->bias; a.bias_per_row = 0;
   a.bias2 = d->bias2; a.bias2_rpg = d->bias2_rows_per_group > 0 ? d->bias2_rows_per_group : 1;
+  a.bias2_ld = d->bias2_ld > 0 ? d->bias2_ld : d->Cout;
   a.rowscale = nullptr;
   a.residual = d->residual; a.ldr = d->ldr > 0 ? d->ldr : d->Cout; a.sR = 0;
   a.alpha = d->alpha; a.act = d->act; a.out_f32 = 0;

@@ -28,6 +28,7 @@ class GemmDesc(C.Structure):
         ("bias_per_row", C.c_int),
         ("bias2", C.c_void_p),
         ("bias2_rows_per_group", C.c_int),
+        ("bias2_ld", C.c_int64),
         ("rowscale", C.c_void_p),
         ("residual", C.c_void_p),
         ("ldr", C.c_int64),
@@ -48,6 +49,7 @@ class ConvDesc(C.Structure):
         ("bias", C.c_void_p),
         ("bias2", C.c_void_p),
         ("bias2_rows_per_group", C.c_int),
+        ("bias2_ld", C.c_int64),
         ("residual", C.c_void_p),
         ("ldr", C.c_int64),
         ("ldy", C.c_int64),
@@ -111,6 +113,10 @@ def load(path=None):
         raise HalloLibraryError(
             f"{p} not found: build it with `python -m hallo_amd.build` (hipcc --offload-arch=gfx950). "
             "hallo_amd has no CPU / PyTorch fallback.")
+    # The process must hold ONE HIP runtime: torch bundles its own libamdhip64.so.7 and the streams / device
+    # pointers handed to this library come from it.  Importing torch first makes the dynamic loader bind
+    # libhallo_amd.so's NEEDED libamdhip64.so.7 to the already-loaded copy instead of /opt/rocm's.
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(p)
     except OSError as e:  # pragma: no cover - depends on the host's ROCm install

@@ -1,0 +1,190 @@
+"""Transformer blocks of the Hallo hot path on token-major `[frames, H*W, C]` activations.
+
+Reference classes (hallo/models/attention.py): BasicTransformerBlock 79-407 (ReferenceNet),
+TemporalBasicTransformerBlock 410-618 (spatial block of the denoising UNet),
+AudioTemporalBasicTransformerBlock 621-907 (hierarchical audio cross-attention), with the
+forwards that ReferenceAttentionControl installs on the first two
+(hallo/models/mutual_self_attention.py:174-368).
+
+What is different from the reference, by design:
+  * the reference-feature coupling is explicit data flow (a `ReferenceBank` written by the
+    ReferenceNet blocks and read by the denoising blocks) instead of forward monkey-patching;
+  * [self ; reference] K/V is never concatenated: hallo_attention walks two K/V segments, and the
+    CFG rule "uncond rows attend to themselves only" (mutual_self_attention.py:264-284) is a per-row
+    segment extent, not a second attention pass over half the batch + masked scatter;
+  * everything that is constant across the DDIM steps of a clip -- K/V of the reference bank,
+    of the 4 face tokens and of the 32 audio tokens per frame -- is projected once per clip
+    (`ClipCache`), not once per step;
+  * q/k/v projections that share an input are single fused GEMMs, GEGLU and residual adds run in
+    GEMM epilogues, the audio mask multiply is a GEMM row scale.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from .layers import Attention, Conv1x1, FeedForward, LayerNorm
+
+
+class ClipCache:
+    """Per-clip store of step-invariant tensors, keyed by (module id, tag).  Owned by the pipeline
+    (or absent: then everything is recomputed per call, which is what a bare
+    `UNet3DConditionModel.forward` drop-in call does)."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, mod, tag, make):
+        k = (id(mod), tag)
+        v = self._d.get(k)
+        if v is None:
+            v = make()
+            self._d[k] = v
+        return v
+
+    def clear(self):
+        self._d.clear()
+
+
+class _NoCache:
+    def get(self, mod, tag, make):
+        return make()
+
+
+NO_CACHE = _NoCache()
+
+
+class BasicTransformerBlock(nn.Module):
+    """ReferenceNet block in write mode (mutual_self_attention.py:223-232, 329-368): banks norm1(x), then
+    self-attention, face-token cross-attention, GEGLU feed-forward."""
+
+    def __init__(self, dim, heads, head_dim, cross_attention_dim):
+        super().__init__()
+        self.norm1 = LayerNorm(dim)
+        self.attn1 = Attention(dim, None, heads, head_dim)
+        self.norm2 = LayerNorm(dim)
+        self.attn2 = Attention(dim, cross_attention_dim, heads, head_dim)
+        self.norm3 = LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def run(self, x, enc, bank_out):
+        """x [n, L, C]; enc [Be, T, Cx]; bank_out: list that receives norm1(x) (the reference feature)."""
+        n = x.shape[0]
+        nh = self.norm1.run(x)
+        bank_out.append(nh)
+        _, q, k, v = self.attn1.qkv(nh)
+        a = ops.attention(q, k, v, self.attn1.heads)
+        x = self.attn1.out(a, residual=x)
+        nh = self.norm2.run(x)
+        # mutual_self_attention.py:341-349: `encoder_hidden_states.repeat(tmp, 1, 1)` TILES the face tokens
+        # over the image axis, so image i attends to enc[i % Be] (uncond/cond alternate under CFG).
+        k2, v2 = self.attn2.kv(enc)
+        rep = n // enc.shape[0]
+        k2, v2 = k2.repeat(rep, 1, 1), v2.repeat(rep, 1, 1)
+        q2 = self.attn2.to_q.run(nh.view(-1, nh.shape[-1])).view(n, -1, self.attn2.inner)
+        a = ops.attention(q2, k2, v2, self.attn2.heads)
+        x = self.attn2.out(a, residual=x)
+        return self.ff.run(self.norm3.run(x), residual=x)
+
+
+class TemporalBasicTransformerBlock(nn.Module):
+    """Spatial block of the denoising UNet in read mode (mutual_self_attention.py:174-327)."""
+
+    def __init__(self, dim, heads, head_dim, cross_attention_dim):
+        super().__init__()
+        self.attn1 = Attention(dim, None, heads, head_dim)
+        self.norm1 = LayerNorm(dim)
+        self.attn2 = Attention(dim, cross_attention_dim, heads, head_dim)
+        self.norm2 = LayerNorm(dim)
+        self.ff = FeedForward(dim)
+        self.norm3 = LayerNorm(dim)
+
+    def run(self, x, enc, bank, video_length, do_cfg, cache=NO_CACHE):
+        """x [n = b*f, L, C]; enc [b, T, Cx] face tokens; bank [b*s, L, C] (s = 1 reference + motion frames,
+        fp16-rounded: ReferenceAttentionControl.update casts to fp16 whatever the run dtype, :404,452)."""
+        n, L, Cd = x.shape
+        b = n // video_length
+        a1 = self.attn1
+
+        def bank_kv():
+            ref = bank.view(b, -1, L, Cd)[:, 0].to(x.dtype)      # d_b[:, 0]: the reference image's features
+            return a1.kv(ref.contiguous())
+        k2, v2 = cache.get(self, "bank_kv", bank_kv)
+
+        nh = self.norm1.run(x)
+        _, q, k, v = a1.qkv(nh)
+        # K/V = [self ; bank]: frame row r reads bank entry r % b (the reference's `.repeat(1, f, 1, 1)` on the
+        # 3-D tensor tiles the batch axis, mutual_self_attention.py:235-247); with CFG the first half of the
+        # rows (uncond) skips the bank segment (:264-284).
+        a = ops.attention(q, k, v, a1.heads, k2=k2, v2=v2, kv2_batch_div=1, kv2_batch_mod=b,
+                          kv2_first_batch=(n // 2 if do_cfg else 0))
+        x = a1.out(a, residual=x)
+
+        a2 = self.attn2
+
+        def face_kv():
+            kf, vf = a2.kv(enc)                                   # [b, T, C]
+            T = kf.shape[1]
+            # "b n c -> (b f) n c" (transformer_3d.py:189-192): frame row r uses enc[r // f]
+            ex = lambda t: t.unsqueeze(1).expand(b, video_length, T, Cd).reshape(n, T, Cd)
+            return ex(kf), ex(vf)
+        kf, vf = cache.get(self, "face_kv", face_kv)
+        nh = self.norm2.run(x)
+        q2 = a2.to_q.run(nh.view(n * L, Cd)).view(n, L, Cd)
+        a = ops.attention(q2, kf, vf, a2.heads)
+        x = a2.out(a, residual=x)
+        return self.ff.run(self.norm3.run(x), residual=x)
+
+
+class AudioTemporalBasicTransformerBlock(nn.Module):
+    """hallo/models/attention.py:621-907: self-attention, then three cross-attentions to the frame's 32
+    audio tokens, each masked by the full / face / lip region mask of this block's depth, passed through a
+    zero-initialised 1x1 conv, weighted by motion_scale and summed into the residual; GEGLU feed-forward."""
+
+    def __init__(self, dim, heads, head_dim, cross_attention_dim, depth):
+        super().__init__()
+        self.depth = depth
+        self.zero_conv_full = Conv1x1(dim, dim)
+        self.zero_conv_face = Conv1x1(dim, dim)
+        self.zero_conv_lip = Conv1x1(dim, dim)
+        self.attn1 = Attention(dim, None, heads, head_dim)
+        self.norm1 = LayerNorm(dim)
+        self.attn2_0 = Attention(dim, cross_attention_dim, heads, head_dim)
+        self.attn2_1 = Attention(dim, cross_attention_dim, heads, head_dim)
+        self.attn2_2 = Attention(dim, cross_attention_dim, heads, head_dim)
+        self.norm2 = LayerNorm(dim)
+        self.ff = FeedForward(dim)
+        self.norm3 = LayerNorm(dim)
+
+    def _prepare(self):
+        xs = (self.attn2_0, self.attn2_1, self.attn2_2)
+        self.w_q3 = torch.cat([a.to_q.weight for a in xs], dim=0).contiguous()         # [3D, D]
+        self.w_kv3 = torch.cat([torch.cat([a.to_k.weight, a.to_v.weight], 0) for a in xs], 0).contiguous()  # [6D, Ca]
+
+    def run(self, x, audio, masks, motion_scale, cache=NO_CACHE):
+        """x [n, L, D]; audio [n, 32, Ca]; masks = (full, face, lip), each fp32 [n, L] for this block's depth."""
+        n, L, D = x.shape
+        nh = self.norm1.run(x)
+        _, q, k, v = self.attn1.qkv(nh)
+        a = ops.attention(q, k, v, self.attn1.heads)
+        x = self.attn1.out(a, residual=x)
+
+        def audio_kv():
+            T = audio.shape[1]
+            return ops.gemm(audio.reshape(n * T, -1), self.w_kv3).view(n, T, 6 * D)
+        kv3 = cache.get(self, "audio_kv", audio_kv)
+
+        nh = self.norm2.run(x)
+        q3 = ops.gemm(nh.view(n * L, D), self.w_q3).view(n, L, 3 * D)
+        attns = (self.attn2_0, self.attn2_1, self.attn2_2)
+        convs = (self.zero_conv_full, self.zero_conv_face, self.zero_conv_lip)
+        acc = x.view(n * L, D)
+        for i in range(3):
+            a = ops.attention(q3[:, :, i * D:(i + 1) * D], kv3[:, :, 2 * i * D:(2 * i + 1) * D],
+                              kv3[:, :, (2 * i + 1) * D:(2 * i + 2) * D], attns[i].heads)
+            # (to_out(a) + bias) * mask  -- attention.py:846-884
+            h = attns[i].to_out[0].run(a.view(n * L, D), rowscale=masks[i].reshape(-1))
+            # motion_scale[i] * zero_conv(h) + running sum  -- attention.py:865-903
+            ms = 1.0 if motion_scale is None else float(motion_scale[i])
+            acc = convs[i].run(h, alpha=ms, residual=acc)
+        x = acc.view(n, L, D)
+        return self.ff.run(self.norm3.run(x), residual=x)

@@ -1,0 +1,93 @@
+"""AnimateDiff-style temporal ("motion") module on token-major activations.
+
+Reference: hallo/models/motion_module.py -- VanillaTemporalModule 126-198,
+TemporalTransformer3DModel 200-316, TemporalTransformerBlock 319-423, PositionalEncoding 426-461,
+VersatileAttention 464-609.  The reference rearranges `(b f) d c -> (b d) f c` before every
+temporal attention and back after it (4 transposes of the whole activation per module); here
+hallo_temporal_attention gathers the F' frame rows of a pixel straight from the
+`[b*F', H*W, 3C]` fused projection, the sinusoidal position table is added inside the LayerNorm
+kernel, and q/k/v are one fused GEMM.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+from .layers import Attention, FeedForward, GroupNorm, LayerNorm, Linear
+
+
+class PositionalEncoding(nn.Module):
+    """Parameter-free; owns the `pe` buffer ([1, max_len, d_model]) that the reference checkpoints carry."""
+
+    def __init__(self, d_model, max_len=24):
+        super().__init__()
+        position = torch.arange(max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(1, max_len, d_model)
+        pe[0, :, 0::2] = torch.sin(position * div_term)
+        pe[0, :, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe)
+
+    def _prepare(self):
+        # the buffer follows the model dtype (fp16 in the reference run); the kernel adds it in fp32
+        self.pe32 = self.pe[0].float().contiguous()
+
+
+class VersatileAttention(Attention):
+    def __init__(self, query_dim, heads, dim_head, max_len):
+        super().__init__(query_dim, None, heads, dim_head)
+        self.pos_encoder = PositionalEncoding(query_dim, max_len=max_len)
+
+
+class TemporalTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, head_dim, n_attn, max_len):
+        super().__init__()
+        self.attention_blocks = nn.ModuleList([VersatileAttention(dim, heads, head_dim, max_len) for _ in range(n_attn)])
+        self.norms = nn.ModuleList([LayerNorm(dim) for _ in range(n_attn)])
+        self.ff = FeedForward(dim)
+        self.ff_norm = LayerNorm(dim)
+
+    def run(self, h, batch, frames):
+        """h [batch*frames, L, C]"""
+        n, L, Cd = h.shape
+        for attn, norm in zip(self.attention_blocks, self.norms):
+            # LN(h) + PE[frame]: row r = (b*frames + f)*L + pixel -> position (r / L) % frames
+            nh = norm.run(h, pe=attn.pos_encoder.pe32, pe_rows_per_pos=L, pe_len=frames)
+            qkv = ops.gemm(nh.view(n * L, Cd), attn.w_qkv).view(n, L, 3 * Cd)
+            a = ops.temporal_attention(qkv, batch, frames, L, Cd, attn.heads)
+            h = attn.out(a, residual=h)
+        return self.ff.run(self.ff_norm.run(h), residual=h)
+
+
+class TemporalTransformer3DModel(nn.Module):
+    def __init__(self, in_channels, heads, head_dim, num_layers, n_attn, max_len, norm_num_groups=32):
+        super().__init__()
+        inner = heads * head_dim
+        self.inner = inner
+        self.norm = GroupNorm(norm_num_groups, in_channels, 1e-6)
+        self.proj_in = Linear(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList(
+            [TemporalTransformerBlock(inner, heads, head_dim, n_attn, max_len) for _ in range(num_layers)])
+        self.proj_out = Linear(inner, in_channels)
+
+    def run(self, x, batch, frames):
+        n, L, Cd = x.shape
+        h = self.norm.run(x)
+        h = self.proj_in.run(h.view(n * L, Cd)).view(n, L, self.inner)
+        for blk in self.transformer_blocks:
+            h = blk.run(h, batch, frames)
+        return self.proj_out.run(h.view(n * L, self.inner), residual=x.view(n * L, Cd)).view(n, L, Cd)
+
+
+class VanillaTemporalModule(nn.Module):
+    def __init__(self, in_channels, num_attention_heads=8, num_transformer_block=1,
+                 attention_block_types=("Temporal_Self", "Temporal_Self"), temporal_position_encoding=True,
+                 temporal_position_encoding_max_len=32, temporal_attention_dim_div=1, norm_num_groups=32):
+        super().__init__()
+        self.temporal_transformer = TemporalTransformer3DModel(
+            in_channels, num_attention_heads, in_channels // num_attention_heads // temporal_attention_dim_div,
+            num_transformer_block, len(attention_block_types), temporal_position_encoding_max_len, norm_num_groups)
+
+    def run(self, x, batch, frames):
+        return self.temporal_transformer.run(x, batch, frames)

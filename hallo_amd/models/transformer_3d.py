@@ -1,0 +1,43 @@
+"""Transformer3DModel (spatial and audio variants) on token-major activations.
+
+Reference: hallo/models/transformer_3d.py:38-257.  The reference reshapes `(b c f h w) ->
+((b f) c h w)`, runs GroupNorm + a 1x1 conv, permutes to tokens, runs the block, permutes back,
+runs a 1x1 conv and permutes to 5-D again (4 full-tensor layout copies per call); on the
+`[frames, H*W, C]` layout all of these are no-ops and the 1x1 convs are plain GEMMs whose
+epilogue carries the residual add.
+"""
+from torch import nn
+
+from .attention import NO_CACHE, AudioTemporalBasicTransformerBlock, TemporalBasicTransformerBlock
+from .layers import Conv1x1, GroupNorm
+
+
+class Transformer3DModel(nn.Module):
+    def __init__(self, heads, head_dim, in_channels, cross_attention_dim, norm_num_groups=32, use_audio_module=False,
+                 depth=0):
+        super().__init__()
+        inner = heads * head_dim
+        self.use_audio_module = use_audio_module
+        self.inner = inner
+        self.norm = GroupNorm(norm_num_groups, in_channels, 1e-6)
+        self.proj_in = Conv1x1(in_channels, inner)
+        if use_audio_module:
+            blk = AudioTemporalBasicTransformerBlock(inner, heads, head_dim, cross_attention_dim, depth)
+        else:
+            blk = TemporalBasicTransformerBlock(inner, heads, head_dim, cross_attention_dim)
+        self.transformer_blocks = nn.ModuleList([blk])
+        self.proj_out = Conv1x1(inner, in_channels)
+
+    def run_spatial(self, x, enc, bank, video_length, do_cfg, cache=NO_CACHE):
+        n, L, Cd = x.shape
+        h = self.norm.run(x)
+        h = self.proj_in.run(h.view(n * L, Cd)).view(n, L, self.inner)
+        h = self.transformer_blocks[0].run(h, enc, bank, video_length, do_cfg, cache)
+        return self.proj_out.run(h.view(n * L, self.inner), residual=x.view(n * L, Cd)).view(n, L, Cd)
+
+    def run_audio(self, x, audio, masks, motion_scale, cache=NO_CACHE, out=None):
+        n, L, Cd = x.shape
+        h = self.norm.run(x)
+        h = self.proj_in.run(h.view(n * L, Cd)).view(n, L, self.inner)
+        h = self.transformer_blocks[0].run(h, audio, masks, motion_scale, cache)
+        return self.proj_out.run(h.view(n * L, self.inner), residual=x.view(n * L, Cd), out=out).view(n, L, Cd)

@@ -59,6 +59,7 @@ def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, 
     d.bias_per_row = 1 if bias_per_row else 0
     d.bias2 = bias2.data_ptr() if bias2 is not None else None
     d.bias2_rows_per_group = bias2_rows_per_group
+    d.bias2_ld = bias2.stride(0) if bias2 is not None else 0
     d.rowscale = rowscale.data_ptr() if rowscale is not None else None
     if rowscale is not None:
         assert rowscale.dtype == torch.float32 and rowscale.numel() == M
@@ -86,7 +87,7 @@ def gemm_batched(a, w, out, *, out_f32=False, alpha=1.0, bias=None, bias_per_row
     d.stride_a, d.stride_b, d.stride_c, d.stride_r = a.stride(0), w.stride(0), out.stride(0), 0
     d.bias = bias.data_ptr() if bias is not None else None
     d.bias_per_row = 1 if bias_per_row else 0
-    d.bias2, d.bias2_rows_per_group, d.rowscale, d.residual, d.ldr = None, 0, None, None, 0
+    d.bias2, d.bias2_rows_per_group, d.bias2_ld, d.rowscale, d.residual, d.ldr = None, 0, 0, None, None, 0
     d.alpha, d.act, d.geglu, d.out_f32 = float(alpha), ACT_NONE, 0, 1 if out_f32 else 0
     d.dtype = dtype_code(a.dtype)
     _l.check(_l.load().hallo_gemm(C.byref(d), _stream()), "hallo_gemm(batched)")
@@ -115,6 +116,7 @@ def conv3x3(x, w, bias, n_img, H, W, *, stride=1, pad_t=1, pad_l=1, out_hw=None,
     d.bias = bias.data_ptr() if bias is not None else None
     d.bias2 = bias2.data_ptr() if bias2 is not None else None
     d.bias2_rows_per_group = bias2_rows_per_group
+    d.bias2_ld = bias2.stride(0) if bias2 is not None else 0
     if residual is not None:
         assert residual.is_contiguous()
         d.residual, d.ldr = residual.data_ptr(), residual.shape[-1]

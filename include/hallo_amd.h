@@ -57,6 +57,7 @@ typedef struct hallo_gemm_desc {
   int bias_per_row;
   const void* bias2;         /* [M / bias2_rows_per_group, N], e.g. per-frame time embedding */
   int bias2_rows_per_group;
+  int64_t bias2_ld;          /* row pitch of bias2 in elements, 0 = N (a column slice of a wider buffer) */
   const float* rowscale;     /* [M] fp32, e.g. the audio attention masks */
   const void* residual;      /* [M,N] with leading dimension ldr (may alias C) */
   int64_t ldr;
@@ -86,6 +87,7 @@ typedef struct hallo_conv_desc {
   const void* bias;          /* [Cout] or null */
   const void* bias2;         /* [n_groups, Cout] or null (time embedding per batch entry) */
   int bias2_rows_per_group;  /* output rows (pixels) per bias2 row */
+  int64_t bias2_ld;          /* row pitch of bias2 in elements, 0 = Cout */
   const void* residual;      /* [n_img*OH*OW, Cout] (ld = ldr) or null */
   int64_t ldr;
   int64_t ldy;               /* leading dimension of y, 0 = Cout */

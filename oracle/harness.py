@@ -1,0 +1,97 @@
+"""Shared builders for the parity tests, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py): builds the CPU oracle nets (oracle/hallo_ref.py) with
+deterministic synthetic weights and hands the SAME weights -- through the reference's state-dict key
+names -- to the native hallo_amd models, so both sides compute on identical parameters.
+"""
+import math
+import os
+import sys
+
+import torch
+
+_STANDIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_standin")
+if _STANDIN not in sys.path:
+    sys.path.insert(0, _STANDIN)
+
+from . import hallo_ref as H  # noqa: E402
+
+# Reduced architecture for fast CPU oracle runs: same block layout / quirks as the full model, widths
+# chosen so that every attention head dim is one the kernels are built for (40 / 80 / 160).
+SMALL = dict(block_out_channels=(80, 160, 320, 320), attention_head_dim=2, cross_attention_dim=64, norm_num_groups=16)
+SMALL_MM = dict(num_attention_heads=2)   # motion modules: 80/2 = 40-wide heads (the full model: 320/8)
+SMALL_AUDIO_DIM = 48
+SMALL_VAE = dict(block_out_channels=(32, 32, 64, 64), norm_num_groups=16)
+FULL = dict(block_out_channels=(320, 640, 1280, 1280), attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32)
+
+
+def round_to(sd, dtype):
+    """Round every floating tensor through `dtype` (what loading an fp16/bf16 checkpoint does) -> fp32."""
+    return {k: (v.to(dtype).float() if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def oracle_nets(cfg=SMALL, audio_dim=SMALL_AUDIO_DIM, vae_cfg=SMALL_VAE, dtype=torch.float16, seed=0):
+    """Oracle modules (fp32 compute) whose weights are synthetic values rounded through `dtype`."""
+    from diffusers import AutoencoderKL
+    mm = SMALL_MM if cfg is SMALL else None
+    den = H.UNet3DConditionModel(audio_attention_dim=audio_dim, motion_module_kwargs=mm, **cfg)
+    ref = H.UNet2DConditionModel(**cfg)
+    vae = AutoencoderKL(**vae_cfg)
+    c0 = cfg["block_out_channels"][0]
+    fl = H.FaceLocator(c0)
+    ip = H.ImageProjModel(cfg["cross_attention_dim"], 512, 4)
+    ap = H.AudioProjModel(5, 12, 16, 32, audio_dim, 32)
+    nets = dict(denoising_unet=den, reference_unet=ref, vae=vae, face_locator=fl, imageproj=ip, audioproj=ap)
+    for i, (name, m) in enumerate(nets.items()):
+        H.fill_synthetic_(m, seed + i + 1)
+        m.load_state_dict(round_to(m.state_dict(), dtype))
+        m.eval()
+    return nets
+
+
+def native_nets(oracle, cfg=SMALL, audio_dim=SMALL_AUDIO_DIM, vae_cfg=SMALL_VAE, dtype=torch.float16, device="cuda:0"):
+    """hallo_amd models carrying the oracle's weights (strict state-dict load: key names must match)."""
+    from hallo_amd.models.audio_proj import AudioProjModel
+    from hallo_amd.models.face_locator import FaceLocator
+    from hallo_amd.models.image_proj import ImageProjModel
+    from hallo_amd.models.unet_2d_condition import UNet2DConditionModel
+    from hallo_amd.models.unet_3d import UNet3DConditionModel
+    from hallo_amd.models.vae import AutoencoderKL
+    c0 = cfg["block_out_channels"][0]
+    mm = SMALL_MM if cfg is SMALL else None
+    nets = dict(denoising_unet=UNet3DConditionModel(audio_attention_dim=audio_dim, motion_module_kwargs=mm, **cfg),
+                reference_unet=UNet2DConditionModel(**cfg), vae=AutoencoderKL(**vae_cfg), face_locator=FaceLocator(c0),
+                imageproj=ImageProjModel(cfg["cross_attention_dim"], 512, 4),
+                audioproj=AudioProjModel(5, 12, 16, 32, audio_dim, 32))
+    for name, m in nets.items():
+        missing, unexpected = m.load_state_dict(oracle[name].state_dict(), strict=True)
+        assert not missing and not unexpected
+        m.to(device=device, dtype=dtype)
+        m.prepare()
+    return nets
+
+
+def clip_inputs(size, frames, audio_dim=SMALL_AUDIO_DIM, seed=1234):
+    """Synthetic per-clip inputs, audio already projected to (1, F, 32, audio_dim)."""
+    g = torch.Generator().manual_seed(seed)
+    S, Fr = size, frames
+    lat = S // 8
+    d = dict(ref_image=torch.rand((1, 3, 3, S, S), generator=g) * 2 - 1, face_emb=torch.randn((1, 512), generator=g),
+             audio=torch.randn((1, Fr, 32, audio_dim), generator=g), face_mask=torch.zeros((1, 3, S, S)))
+    d["face_mask"][:, :, S // 4: 3 * S // 4, S // 4: 3 * S // 4] = 1.0
+    mk = lambda: [torch.rand((Fr, (lat // (2 ** l)) ** 2), generator=g) for l in range(4)]
+    d["full"], d["face"], d["lip"] = mk(), mk(), mk()
+    d["latents"] = torch.randn((1, 4, Fr, lat, lat), generator=torch.Generator().manual_seed(42))
+    d["motion_scale"] = [1.0, 0.8, 1.2]
+    return d
+
+
+def rel_l2(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def psnr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    mse = ((a - b) ** 2).mean().item()
+    return 99.0 if mse == 0 else 10.0 * math.log10(1.0 / mse)

@@ -1,0 +1,194 @@
+"""GPU parity tests, module / network / pipeline tier: the native hallo_amd models (HIP kernels through
+the C ABI) against the CPU oracle (oracle/hallo_ref.py, fp32) on identical synthetic weights and inputs.
+
+Architecture: the reduced config of oracle/harness.py (same block layout and quirks as the full
+model -- training-branch block semantics, half-width audio transformers, bank tiling, CFG uncond rule --
+with widths (80,160,320,320) x 2 heads so head dims are 40/80/160).  Weights are rounded through the
+run dtype on both sides; the reference zero-init layers carry non-zero synthetic values.
+
+Tolerances: one UNet evaluation rel-L2 <= 1e-2 (fp16) / 3e-2 (bf16) vs the fp32 oracle;
+end-to-end latents rel-L2 <= 5e-2 and decoded frames PSNR >= 35 dB; schedule indices bit-exact.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+TOL_UNET = {torch.float16: 1e-2, torch.bfloat16: 3e-2}
+TOL_BANK = {torch.float16: 5e-3, torch.bfloat16: 2e-2}
+
+
+@pytest.fixture(scope="module", params=DTYPES, ids=["fp16", "bf16"])
+def nets(request):
+    from oracle import harness as Hn
+    dtype = request.param
+    o = Hn.oracle_nets(dtype=dtype)
+    n = Hn.native_nets(o, dtype=dtype)
+    return dtype, o, n
+
+
+def _rec(report, name, dtype, val, tol):
+    rec = {"test": name, "dtype": str(dtype), "rel_l2": val, "tol_rel_l2": tol}
+    report.append(rec)
+    print(rec)
+
+
+def _banks(o, n, dtype, B, h, gseed=5):
+    g = torch.Generator().manual_seed(gseed)
+    ref_lat = torch.randn((3, 4, h, h), generator=g).to(dtype).float()
+    enc = torch.randn((B, 4, 64), generator=g).to(dtype).float()
+    t0 = torch.tensor(0)
+    with torch.no_grad():
+        ob = o["reference_unet"](ref_lat.repeat(B, 1, 1, 1), t0, enc)
+    n["reference_unet"](ref_lat.repeat(B, 1, 1, 1), 0, enc)
+    return ref_lat, enc, ob, n["reference_unet"].written_banks
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_referencenet_banks(nets, B, report):
+    dtype, o, n = nets
+    from oracle import harness as Hn
+    _, _, ob, nb = _banks(o, n, dtype, B, 16)
+    assert len(ob) == len(nb) == 16
+    worst = 0.0
+    for a, b in zip(nb, ob):
+        assert a.shape == b.shape
+        worst = max(worst, Hn.rel_l2(a, b))
+    _rec(report, f"referencenet_banks[B={B}]", dtype, worst, TOL_BANK[dtype])
+    assert worst <= TOL_BANK[dtype]
+
+
+@pytest.mark.parametrize("do_cfg", [False, True])
+def test_unet3d_forward(nets, do_cfg, report):
+    """UNet3DConditionModel.forward through the reference NCHW signature + ReferenceAttentionControl."""
+    dtype, o, n = nets
+    from oracle import harness as Hn
+    from hallo_amd.models.mutual_self_attention import ReferenceAttentionControl
+    B, Fr, h = (2 if do_cfg else 1), 4, 16
+    ref_lat, enc, ob, _ = _banks(o, n, dtype, B, h)
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(s, generator=g).to(dtype).float()
+    lat = r(B, 4, Fr, h, h)
+    audio = r(B, Fr, 32, Hn.SMALL_AUDIO_DIM)
+    fm = r(B, 80, Fr, h, h)
+    masks = lambda: [torch.rand((B * Fr, (h // 2 ** l) ** 2), generator=g).to(dtype).float() for l in range(4)]
+    full, face, lip = masks(), masks(), masks()
+    ms = [1.0, 0.7, 1.3]
+    t = torch.tensor(959)
+    with torch.no_grad():
+        banks = [b.clone().to(torch.float16) for b in ob]
+        out_o = o["denoising_unet"](lat, t, enc, banks, audio_embedding=audio, mask_cond_fea=fm, full_mask=full,
+                                    face_mask=face, lip_mask=lip, motion_scale=ms, do_cfg=do_cfg)
+    writer = ReferenceAttentionControl(n["reference_unet"], do_classifier_free_guidance=do_cfg, mode="write",
+                                       fusion_blocks="full")
+    reader = ReferenceAttentionControl(n["denoising_unet"], do_classifier_free_guidance=do_cfg, mode="read",
+                                       fusion_blocks="full")
+    reader.update(writer)
+    out_n = n["denoising_unet"](lat, t, enc, audio_embedding=audio, mask_cond_fea=fm, full_mask=full, face_mask=face,
+                                lip_mask=lip, motion_scale=ms).sample
+    reader.clear()
+    writer.clear()
+    assert out_n.shape == out_o.shape and torch.isfinite(out_n).all()
+    v = Hn.rel_l2(out_n, out_o)
+    _rec(report, f"unet3d_forward[cfg={do_cfg}]", dtype, v, TOL_UNET[dtype])
+    assert v <= TOL_UNET[dtype]
+
+
+def test_unet3d_sensitivity(nets):
+    """The comparison must be able to fail: perturbing the audio tokens / motion_scale changes the oracle
+    output by far more than the parity tolerance (guards against numerically invisible sub-paths, F9)."""
+    dtype, o, n = nets
+    from oracle import harness as Hn
+    B, Fr, h = 1, 4, 16
+    _, enc, ob, _ = _banks(o, n, dtype, B, h)
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(s, generator=g)
+    lat, audio, fm = r(B, 4, Fr, h, h), r(B, Fr, 32, Hn.SMALL_AUDIO_DIM), r(B, 80, Fr, h, h)
+    masks = lambda: [torch.rand((B * Fr, (h // 2 ** l) ** 2), generator=g) for l in range(4)]
+    full, face, lip = masks(), masks(), masks()
+    banks = [b.clone().to(torch.float16) for b in ob]
+    run = lambda a, ms, bk: o["denoising_unet"](lat, torch.tensor(500), enc, bk, audio_embedding=a, mask_cond_fea=fm,
+                                                full_mask=full, face_mask=face, lip_mask=lip, motion_scale=ms)
+    with torch.no_grad():
+        base = run(audio, [1.0, 1.0, 1.0], banks)
+        assert Hn.rel_l2(run(audio * 0, [1.0, 1.0, 1.0], banks), base) > 3 * TOL_UNET[dtype]
+        assert Hn.rel_l2(run(audio, [1.0, 0.0, 1.0], banks), base) > 3 * TOL_UNET[dtype]
+        # motion frames (bank[:, 1:]) must matter too: temporal path visible
+        banks2 = [b.clone() for b in banks]
+        for b in banks2:
+            b.view(B, 3, *b.shape[1:])[:, 1:] *= 0
+        assert Hn.rel_l2(run(audio, [1.0, 1.0, 1.0], banks2), base) > 3 * TOL_UNET[dtype]
+
+
+def test_conditioners(nets, report):
+    dtype, o, n = nets
+    from oracle import harness as Hn
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand((1, 3, 2, 64, 64), generator=g).to(dtype).float()
+    e = torch.randn((1, 512), generator=g).to(dtype).float()
+    a = torch.randn((1, 3, 5, 12, 16), generator=g).to(dtype).float()
+    tol = 4e-3 if dtype == torch.float16 else 2e-2
+    with torch.no_grad():
+        for name, inp in (("face_locator", x), ("imageproj", e), ("audioproj", a)):
+            ref = o[name](inp)
+            got = n[name](inp)
+            assert got.shape == ref.shape
+            v = Hn.rel_l2(got, ref)
+            _rec(report, name, dtype, v, tol)
+            assert v <= tol
+
+
+def test_vae(nets, report):
+    dtype, o, n = nets
+    from oracle import harness as Hn
+    g = torch.Generator().manual_seed(9)
+    img = (torch.rand((2, 3, 64, 64), generator=g) * 2 - 1).to(dtype).float()
+    z = torch.randn((2, 4, 8, 8), generator=g).to(dtype).float()
+    tol = 5e-3 if dtype == torch.float16 else 3e-2
+    with torch.no_grad():
+        m_o = o["vae"].encode(img).latent_dist.mean
+        d_o = o["vae"].decode(z).sample
+    m_n = n["vae"].encode(img).latent_dist.mean
+    d_n = n["vae"].decode(z).sample
+    for name, a, b in (("vae_encode_mean", m_n, m_o), ("vae_decode", d_n, d_o)):
+        assert a.shape == b.shape
+        v = Hn.rel_l2(a, b)
+        _rec(report, name, dtype, v, tol)
+        assert v <= tol
+
+
+@pytest.mark.parametrize("guidance", [3.5, 1.0])
+def test_pipeline_end_to_end(nets, guidance, report):
+    """FaceAnimatePipeline.__call__ vs oracle.hallo_ref.animate: 128x128, 4 frames, 4 DDIM steps; per-step
+    latents, schedule indices (bit-exact) and decoded frames."""
+    dtype, o, n = nets
+    from oracle import harness as Hn
+    from oracle import hallo_ref as H
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.scheduler import DDIMScheduler
+    S, Fr, steps = 128, 4, 4
+    d = Hn.clip_inputs(S, Fr)
+    rd = lambda t: t.to(dtype).float()
+    args = (rd(d["ref_image"]), rd(d["face_emb"]), rd(d["audio"]), d["face_mask"], [rd(m) for m in d["full"]],
+            [rd(m) for m in d["face"]], [rd(m) for m in d["lip"]], S, S, Fr, steps, guidance)
+    seen_o, seen_n = [], []
+    vid_o = H.animate(o["vae"], o["reference_unet"], o["denoising_unet"], o["face_locator"], o["imageproj"],
+                      H.make_scheduler(), *args, motion_scale=d["motion_scale"], latents=rd(d["latents"]),
+                      callback=lambda i, t, l: seen_o.append((int(t), l.clone())))
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched)
+    vid_n = pipe(*args, motion_scale=d["motion_scale"], latents=rd(d["latents"]),
+                 callback=lambda i, t, l: seen_n.append((int(t), l.float().cpu()))).videos
+    assert [t for t, _ in seen_n] == [t for t, _ in seen_o] == [999, 749, 499, 249]
+    worst = max(Hn.rel_l2(a, b) for (_, a), (_, b) in zip(seen_n, seen_o))
+    _rec(report, f"pipeline_latents[gs={guidance}]", dtype, worst, 5e-2)
+    assert worst <= 5e-2
+    assert vid_n.shape == vid_o.shape == (1, 3, Fr, S, S) and vid_n.dtype == torch.float32
+    assert float(vid_n.min()) >= 0.0 and float(vid_n.max()) <= 1.0
+    p = Hn.psnr(vid_n, vid_o)
+    report.append({"test": f"pipeline_frames_psnr[gs={guidance}]", "dtype": str(dtype), "psnr_db": p, "tol_psnr_db": 35.0})
+    print("PSNR", p)
+    assert p >= 35.0
