@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[db][r] = 0.0f;
   float m_run = -1e30f, l_run = 0.0f;
+  constexpr float RESCALE_THR = 6.0f;   // log2 units: P <= 64
 
   if (nt > 0) {
     load_tile(0);
@@ -174,45 +175,51 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
       }
     }
 
-    // ---- scale, mask, online softmax (lane-local row; partner lane^32 holds the other kv half) ----
+    // ---- online softmax on the raw scores (lane-local row; partner lane^32 holds the other kv half) ----
+    // p = exp2(s * c - m) with c = scale * log2(e) folded into one FMA per element; v_exp_f32 directly
+    // (scores are bounded, no denormal handling needed).  Only the ragged last tile of a segment is masked.
     const bool s2 = it >= nt1;
     const int L = s2 ? p.Lkv2 : p.Lkv1;
     const int kv0 = (s2 ? it - nt1 : it) * KVB;
-    const bool partial = kv0 + KVB > L;
-    float mx = -1e30f;
+    if (kv0 + KVB > L) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = s[t][r] * p.scale_log2e;
-        if (partial) {
+        for (int r = 0; r < 16; ++r) {
           const int kv = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          v = (kv < L) ? v : -1e30f;
+          s[t][r] = (kv < L) ? s[t][r] : -3.0e38f;
         }
-        s[t][r] = v;
-        mx = fmaxf(mx, v);
-      }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(s[t][r], s[t][r + 1]), mx);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2e;
+    // deferred rescale (keep the old reference max while the row max grew by < 2^RESCALE_THR): the O / l
+    // rescale pass is skipped for most tiles; P stays <= 2^RESCALE_THR, exact in the fp32 accumulators.
+    if (!__all(mx - m_run <= RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
     float psum = 0.0f;
     V8 pf[NT][2];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(s[t][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], p.scale_log2e, -m_run));
         psum += pv;
         pf[t][r >> 3][r & 7] = from_f32<T>(pv);
       }
     }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T . P^T ----
 #pragma unroll

@@ -20,6 +20,7 @@
 // optional stride 2, optional nearest-2x upsample folded into the gather (resnet.py:166-168).
 #include "common.h"
 #include "../../include/hallo_amd.h"
+#include <string.h>
 
 namespace hallo {
 
@@ -43,6 +44,9 @@ struct GemmArgs {
   int act;
   int out_f32;
   int tiles_n, tiles_m;
+  int splits, nk_per_split;   // split-K: blockIdx.y = split, each split owns nk_per_split K tiles
+  float* slab;                // fp32 partial sums [splits][M][N] (splits > 1)
+  int vec_ok, res_vec_ok, bias_vec_ok, bias2_vec_ok;   // 8-byte (fp32: 16-byte) row accesses are aligned
   // conv gather
   int H, W, Cin, OH, OW, stride, pad_t, pad_l, upsample;
 };
@@ -242,14 +246,433 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   }
 }
 
+
+// =============================================================================================
+// v2: direct-to-LDS staging (global_load_lds, 16 B per lane), swizzled through the SOURCE address,
+// swapped-operand MFMA so that every lane owns one output row.
+//
+//  * Each operand tile is [128 rows][64 k] (128 B per row).  One global_load_lds_dwordx4 of a wave writes
+//    1024 contiguous LDS bytes = 8 rows; lane l lands at row (l>>3), physical 16-B chunk (l&7), and fetches
+//    the LOGICAL chunk (l&7) ^ ((row>>1)&7) of that row from global memory (same 128-B line: still coalesced).
+//    Fragment reads apply the same XOR.  With 128-B rows two rows share one 256-B bank row, and
+//    (row&1, (row>>1)&7) is distinct over every 16-lane group ds_read_b128 is serviced in
+//    ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...), so the fragment reads are bank-conflict free.
+//  * No VGPR staging, no ds_write pass: the K loop is {issue 8 LDS-DMA loads, wait, barrier, 16 ds_read_b128
+//    + 16 MFMA per wave, barrier}.  STAGES = 2 keeps the next tile's loads in flight under the current
+//    tile's MFMAs with a counted s_waitcnt vmcnt(8) (raw s_barrier: __syncthreads would drain the DMA queue).
+//  * Out-of-range K chunks and the zero padding of the 3x3 conv gather read a 16-byte zero page.
+//  * MFMA operands are swapped (A = weight rows, B = activation rows): D[n][m], lane owns column m and four
+//    consecutive n per register group -> 8-byte C stores / residual loads instead of 2-byte scattered ones.
+// =============================================================================================
+__device__ uint4 g_zero_page[2];
+
+constexpr int TILE_ELEMS = 128 * 64;
+
+template <typename T, int MODE /*0 gemm, 1 conv3x3, 2 geglu*/, int STAGES>
+__global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs p) {
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  constexpr bool CONV = MODE == 1, GEGLU = MODE == 2;
+  __shared__ __attribute__((aligned(16))) T smem[STAGES * 2 * TILE_ELEMS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = xcd_remap(blockIdx.x, nwg);
+  const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = GEGLU ? tile_n * 64 : tile_n * BN;
+  const long zb = blockIdx.z;
+
+  const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + zb * p.sA;
+  const T* __restrict__ B = reinterpret_cast<const T*>(p.B) + zb * p.sB;
+  const T* zero = reinterpret_cast<const T*>(g_zero_page);
+
+  // ---- loader state: thread owns physical chunk lp of rows r_j = wave*32 + j*8 + lrow, j = 0..3 ----
+  const int lrow = lane >> 3, lp = lane & 7;
+  const int cA = lp ^ (lane >> 4);   // logical chunk of slabs j = 0, 2   ((r_j >> 1) & 7 == (lane >> 4) + 4*(j&1))
+  const int cB = cA ^ 4;             // logical chunk of slabs j = 1, 3
+
+  const T* b_ptr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 32 + j * 8 + lrow;
+    int wrow;
+    if (GEGLU) {
+      const int jw = r >> 6, t = (r >> 5) & 1, c = r & 31;   // tile rows: [wn(2)][value, gate][32]
+      int col = n0 + jw * 32 + c;
+      col = col < p.N ? col : p.N - 1;
+      wrow = t * p.N + col;
+    } else {
+      wrow = n0 + r;
+      wrow = wrow < p.N ? wrow : p.N - 1;
+    }
+    b_ptr[j] = B + (long)wrow * p.ldb;
+  }
+  const T* a_ptr[4];
+  int a_iy[4], a_ix[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int m = m0 + wave * 32 + j * 8 + lrow;
+    if (m >= p.M) m = p.M - 1;
+    if (CONV) {
+      const int hw = p.OH * p.OW;
+      const int img = m / hw, rem = m - img * hw;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      a_iy[j] = oy * p.stride - p.pad_t;
+      a_ix[j] = ox * p.stride - p.pad_l;
+      a_ptr[j] = A + (long)img * p.H * p.W * p.Cin;
+    } else {
+      a_ptr[j] = A + (long)m * p.lda;
+      a_iy[j] = a_ix[j] = 0;
+    }
+  }
+  // conv: (tap, channel) of this thread's two logical chunks in the current K tile
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt_begin = (p.splits > 1) ? blockIdx.y * p.nk_per_split : 0;
+  const int kt_end = (p.splits > 1) ? min(nk_all, kt_begin + p.nk_per_split) : nk_all;
+  int tapA = 0, chA = 0, tapB = 0, chB = 0;
+  if (CONV) {
+    const int k0 = kt_begin * BK;
+    tapA = (k0 + cA * 8) / p.Cin; chA = k0 + cA * 8 - tapA * p.Cin;
+    tapB = (k0 + cB * 8) / p.Cin; chB = k0 + cB * 8 - tapB * p.Cin;
+  }
+  const int VH = CONV ? (p.upsample ? 2 * p.H : p.H) : 0;
+  const int VW = CONV ? (p.upsample ? 2 * p.W : p.W) : 0;
+
+  auto stage = [&](int kt, int buf) {
+    T* sA = smem + buf * 2 * TILE_ELEMS;
+    T* sB = sA + TILE_ELEMS;
+    const int kA = kt * BK + cA * 8, kB = kt * BK + cB * 8;
+    int kyA = 0, kxA = 0, kyB = 0, kxB = 0;
+    if (CONV) {
+      kyA = tapA / 3; kxA = tapA - kyA * 3;
+      kyB = tapB / 3; kxB = tapB - kyB * 3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = (j & 1) ? kB : kA;
+      const bool kin = kk < p.K;
+      const T* sb = kin ? b_ptr[j] + kk : zero;
+      const T* sa;
+      if (CONV) {
+        const int ky = (j & 1) ? kyB : kyA, kx = (j & 1) ? kxB : kxA, ch = (j & 1) ? chB : chA;
+        const int vy = a_iy[j] + ky, vx = a_ix[j] + kx;
+        const bool inb = kin && vy >= 0 && vy < VH && vx >= 0 && vx < VW;
+        const int sy = p.upsample ? (vy >> 1) : vy, sx = p.upsample ? (vx >> 1) : vx;
+        sa = inb ? a_ptr[j] + ((long)sy * p.W + sx) * p.Cin + ch : zero;
+      } else {
+        sa = kin ? a_ptr[j] + kk : zero;
+      }
+      const int slab = (wave * 32 + j * 8) * BK;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                       (__attribute__((address_space(3))) void*)(sA + slab), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                       (__attribute__((address_space(3))) void*)(sB + slab), 16, 0, 0);
+    }
+    if (CONV) {
+      chA += BK; while (chA >= p.Cin) { chA -= p.Cin; ++tapA; }
+      chB += BK; while (chB >= p.Cin) { chB -= p.Cin; ++tapB; }
+    }
+  };
+
+  f32x16 acc[2][2];   // [tn][tm]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // fragment read offsets: row = base + l31, logical chunk ks*2 + hi -> physical (ks*2) ^ (hi ^ ((l31>>1)&7))
+  const int xsw = hi ^ ((l31 >> 1) & 7);
+  const int fa_row = (wm * 64 + l31) * BK;
+  const int fb_row = (wn * 64 + l31) * BK;
+
+  auto compute = [&](int buf) {
+    const T* sA = smem + buf * 2 * TILE_ELEMS;
+    const T* sB = sA + TILE_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int co = ((ks * 2) ^ xsw) * 8;
+      V8 a0 = ld8<T>(sA + fa_row + co);
+      V8 a1 = ld8<T>(sA + fa_row + 32 * BK + co);
+      V8 w0 = ld8<T>(sB + fb_row + co);
+      V8 w1 = ld8<T>(sB + fb_row + 32 * BK + co);
+      acc[0][0] = Vec<T>::mfma32(w0, a0, acc[0][0]);
+      acc[0][1] = Vec<T>::mfma32(w0, a1, acc[0][1]);
+      acc[1][0] = Vec<T>::mfma32(w1, a0, acc[1][0]);
+      acc[1][1] = Vec<T>::mfma32(w1, a1, acc[1][1]);
+    }
+  };
+
+  if (STAGES == 1) {
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      stage(kt, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      compute(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    if (kt_begin < kt_end) stage(kt_begin, kt_begin & 1);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      if (kt + 1 < kt_end) {
+        stage(kt + 1, (kt + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile kt landed, tile kt+1 (8 DMA loads) in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      compute(kt & 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // fragment reads done before the buffer is released
+      __builtin_amdgcn_s_barrier();                          // buffer kt&1 is free for tile kt+2
+    }
+  }
+
+  // ---- epilogue ----
+  // The accumulators hold D[n][m] (lane: column m = l31, rows n = 8g + 4hi + 0..3): stored directly, every lane
+  // would write 8 bytes at a row stride -- 32 partial lines per store instruction.  Instead each wave transposes
+  // its 32 x 64 fp32 half-tile through its own 8 KB slice of the (now idle) staging LDS, XOR-swizzled in 16-byte
+  // chunks (chunk ^ (row & 15): conflict-free ds_write_b128 and ds_read_b128), and then every lane owns 8
+  // consecutive n of one row: bias / residual loads and the C store are 16 bytes per lane, 128 contiguous
+  // bytes per row, 8 rows per instruction.
+  const T* bias = reinterpret_cast<const T*>(p.bias);
+  const T* bias2 = reinterpret_cast<const T*>(p.bias2);
+  const T* res = p.residual ? reinterpret_cast<const T*>(p.residual) + zb * p.sR : nullptr;
+  T* C = reinterpret_cast<T*>(p.C) + zb * p.sC;
+  float* Cf = reinterpret_cast<float*>(p.C) + zb * p.sC;
+  float* tile = reinterpret_cast<float*>(smem) + wave * (32 * 64);   // [32 rows][16 chunks of 4 fp32]
+
+  auto ld8f = [&](const T* ptr, bool aligned, float* o) {   // 8 consecutive elements -> fp32
+    if (aligned) {
+      V8 v = ld8<T>(ptr);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = to_f32(v[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = to_f32(ptr[j]);
+    }
+  };
+
+  const int rr0 = lane >> 3;            // read phase: rows rr0 + 8 i
+  const int rc = lane & 7;              // read phase: 8-column (GEGLU: 4-column) group
+  // per-column bias of this lane's columns, loaded once
+  float bcol[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (bias && !p.bias_per_row) {
+    if (GEGLU) {
+      const int n = n0 + wn * 32 + rc * 4;
+      if (n < p.N) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bcol[j] = to_f32(bias[n + j]); bcol[4 + j] = to_f32(bias[p.N + n + j]); }
+      }
+    } else {
+      const int n = n0 + wn * 64 + rc * 8;
+      if (n < p.N) ld8f(bias + n, p.bias_vec_ok, bcol);
+    }
+  }
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    // ---- write phase: acc[tn][tm] -> tile[row = l31][col = tn*32 + 8g + 4hi + 0..3] ----
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int chunk = (tn * 8 + 2 * g + hi) ^ (l31 & 15);
+        *reinterpret_cast<f32x4*>(tile + l31 * 64 + chunk * 4) =
+            f32x4{acc[tn][tm][g * 4], acc[tn][tm][g * 4 + 1], acc[tn][tm][g * 4 + 2], acc[tn][tm][g * 4 + 3]};
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- read phase ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = rr0 + 8 * i;
+      const int m = m0 + wm * 64 + tm * 32 + rr;
+      if (GEGLU) {
+        const int n = n0 + wn * 32 + rc * 4;
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(tile + rr * 64 + ((rc ^ (rr & 15)) * 4));
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(tile + rr * 64 + (((8 + rc) ^ (rr & 15)) * 4));
+        if (m < p.M && n < p.N) {
+          V4 w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = from_f32<T>((hv[j] + bcol[j]) * gelu_erf_f(gv[j] + bcol[4 + j]));
+          *reinterpret_cast<V4*>(C + (long)m * p.ldc + n) = w;
+        }
+      } else {
+        const int n = n0 + wn * 64 + rc * 8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(tile + rr * 64 + (((2 * rc) ^ (rr & 15)) * 4));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(tile + rr * 64 + (((2 * rc + 1) ^ (rr & 15)) * 4));
+        if (p.splits > 1) {
+          if (m < p.M && n < p.N) {
+            float* sp = p.slab + ((long)blockIdx.y * p.M + m) * p.N + n;
+            *reinterpret_cast<f32x4*>(sp) = v0;
+            *reinterpret_cast<f32x4*>(sp + 4) = v1;
+          }
+        } else if (m < p.M && n < p.N) {
+          float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          float t8[8];
+          const float br = (bias && p.bias_per_row) ? to_f32(bias[m]) : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += bcol[j] + br;
+          if (bias2) {
+            ld8f(bias2 + (long)(m / p.bias2_rpg) * p.bias2_ld + n, p.bias2_vec_ok, t8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += t8[j];
+          }
+          const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] *= rs;
+          if (res) {
+            ld8f(res + (long)m * p.ldr + n, p.res_vec_ok, t8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += t8[j];
+          }
+          if (p.act == ACT_SILU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = silu_f(o[j]);
+          } else if (p.act == ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.0f);
+          }
+          if (p.out_f32) {
+            float* cp = Cf + (long)m * p.ldc + n;
+            *reinterpret_cast<f32x4*>(cp) = f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(cp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+          } else {
+            V8 w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = from_f32<T>(o[j]);
+            st8<T>(C + (long)m * p.ldc + n, w);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // this wave's reads are issued (LDS is in-order per wave) before the next half's writes
+  }
+  // shapes without 16-byte aligned rows (N % 8 != 0, e.g. the 3-channel image conv) are routed to the v1 kernel by the host
+}
+
+
+// Split-K second pass: out[m, n..n+7] = epilogue( sum_s slab[s][m][n..] ) in a fixed split order (deterministic).
 template <typename T>
-static int launch_gemm(const GemmArgs& a, bool conv, bool geglu, int batch, hipStream_t st) {
-  dim3 grid(a.tiles_m * a.tiles_n, 1, batch), block(256);
-  if (geglu) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, st, a);
-  else if (conv) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, st, a);
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+  using V8 = typename Vec<T>::v8;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n8 = p.N / 8;
+  if (idx >= (long)p.M * n8) return;
+  const int m = (int)(idx / n8), n = (int)(idx - (long)m * n8) * 8;
+  float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int sidx = 0; sidx < p.splits; ++sidx) {
+    const float* sp = p.slab + ((long)sidx * p.M + m) * p.N + n;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] += a[j]; o[4 + j] += b[j]; }
+  }
+  const T* bias = reinterpret_cast<const T*>(p.bias);
+  const T* bias2 = reinterpret_cast<const T*>(p.bias2);
+  const T* res = reinterpret_cast<const T*>(p.residual);
+  if (bias) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] += p.bias_per_row ? to_f32(bias[m]) : to_f32(bias[n + j]);
+  }
+  if (bias2) {
+    const T* b2 = bias2 + (long)(m / p.bias2_rpg) * p.bias2_ld + n;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] += to_f32(b2[j]);
+  }
+  const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] *= rs;
+  if (res) {
+    const T* rp = res + (long)m * p.ldr + n;
+    if (p.res_vec_ok) {
+      V8 r8 = ld8<T>(rp);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += to_f32(r8[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += to_f32(rp[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (p.act == ACT_SILU) o[j] = silu_f(o[j]);
+    else if (p.act == ACT_RELU) o[j] = fmaxf(o[j], 0.0f);
+  }
+  if (p.out_f32) {
+    float* cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+    *reinterpret_cast<f32x4*>(cp) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(cp + 4) = f32x4{o[4], o[5], o[6], o[7]};
+  } else {
+    V8 w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = from_f32<T>(o[j]);
+    st8<T>(reinterpret_cast<T*>(p.C) + (long)m * p.ldc + n, w);
+  }
+}
+
+static int g_gemm_variant = 3;   // 0: v1 (register-staged), 1 / 2: v2 with 1 / 2 LDS stages, 3: auto (1 or 2 by grid size)
+static int g_split_k = 1;        // 0: never split K, 1: auto
+
+
+template <typename T>
+static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
+  const int tiles = a.tiles_m * a.tiles_n;
+  int v = a.vec_ok ? g_gemm_variant : 0;
+  // auto: one LDS stage (4 workgroups per CU hide each other's load latency) when the grid fills the chip several
+  // times over, two stages (in-workgroup prefetch) for small grids
+  if (v == 3) v = (tiles * batch >= 640) ? 1 : 2;
+  a.splits = 1; a.nk_per_split = 0; a.slab = nullptr;
+  const int nk = (a.K + BK - 1) / BK;
+  if (v != 0 && !geglu && batch == 1 && g_split_k && ws && tiles < 384 && nk >= 8) {
+    // small grids with a long K loop (8x8 / 16x16 feature maps, K up to 23040): split K so that >= ~768 workgroups
+    // are in flight; partial sums go to an fp32 slab and a second pass applies the epilogue in a fixed order
+    int sp = (768 + tiles - 1) / tiles;
+    if (sp > nk / 4) sp = nk / 4;
+    if (sp > 16) sp = 16;
+    while (sp > 1 && (int64_t)sp * a.M * a.N * 4 > ws_bytes) --sp;
+    if (sp > 1) {
+      a.nk_per_split = (nk + sp - 1) / sp;
+      a.splits = (nk + a.nk_per_split - 1) / a.nk_per_split;
+      a.slab = reinterpret_cast<float*>(ws);
+    }
+  }
+  dim3 grid(tiles, a.splits, batch), block(256);
+  if (v == 0) {
+    if (geglu) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, st, a);
+    else if (conv) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, st, a);
+  } else if (v == 1) {
+    if (geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 1>), grid, block, 0, st, a);
+    else if (conv) hipLaunchKernelGGL((gemm2_kernel<T, 1, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm2_kernel<T, 0, 1>), grid, block, 0, st, a);
+  } else {
+    if (geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 2>), grid, block, 0, st, a);
+    else if (conv) hipLaunchKernelGGL((gemm2_kernel<T, 1, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm2_kernel<T, 0, 2>), grid, block, 0, st, a);
+  }
   HALLO_CHECK_LAUNCH();
+  if (a.splits > 1) {
+    const long n = (long)a.M * (a.N / 8);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((n + 255) / 256)), block, 0, st, a);
+    HALLO_CHECK_LAUNCH();
+  }
   return 0;
+}
+
+static void set_vec_flags(GemmArgs& a, int esz_out) {
+  // C rows: 4 consecutive elements per store -> ldc % 4 and an 8-byte (fp32: 16-byte) aligned base
+  const uintptr_t cp = reinterpret_cast<uintptr_t>(a.C);
+  a.vec_ok = (a.N % 8 == 0) && (a.ldc % 8 == 0) && (cp % 16 == 0) && ((a.sC * esz_out) % 16 == 0);
+  a.bias_vec_ok = a.bias && reinterpret_cast<uintptr_t>(a.bias) % 16 == 0;
+  a.bias2_vec_ok = a.bias2 && reinterpret_cast<uintptr_t>(a.bias2) % 16 == 0 && a.bias2_ld % 8 == 0;
+  const uintptr_t rp = reinterpret_cast<uintptr_t>(a.residual);
+  a.res_vec_ok = a.residual && (a.ldr % 8 == 0) && (rp % 16 == 0) && ((a.sR * 2) % 16 == 0);
 }
 
 }  // namespace hallo
@@ -276,9 +699,10 @@ extern "C" int hallo_gemm(const hallo_gemm_desc* d, void* stream) {
   a.tiles_m = (d->M + BM - 1) / BM;
   a.tiles_n = d->geglu ? (d->N + 63) / 64 : (d->N + BN - 1) / BN;
   a.H = a.W = a.Cin = a.OH = a.OW = a.stride = a.pad_t = a.pad_l = a.upsample = 0;
+  set_vec_flags(a, d->out_f32 ? 4 : 2);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (d->dtype == DT_F16) return launch_gemm<_Float16>(a, false, d->geglu != 0, d->batch, st);
-  if (d->dtype == DT_BF16) return launch_gemm<__bf16>(a, false, d->geglu != 0, d->batch, st);
+  if (d->dtype == DT_F16) return launch_gemm<_Float16>(a, false, d->geglu != 0, d->batch, d->workspace, d->workspace_bytes, st);
+  if (d->dtype == DT_BF16) return launch_gemm<__bf16>(a, false, d->geglu != 0, d->batch, d->workspace, d->workspace_bytes, st);
   return -22;
 }
 
@@ -302,8 +726,16 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
   a.tiles_n = (a.N + BN - 1) / BN;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW;
   a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.upsample = d->upsample;
+  set_vec_flags(a, 2);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (d->dtype == DT_F16) return launch_gemm<_Float16>(a, true, false, 1, st);
-  if (d->dtype == DT_BF16) return launch_gemm<__bf16>(a, true, false, 1, st);
+  if (d->dtype == DT_F16) return launch_gemm<_Float16>(a, true, false, 1, d->workspace, d->workspace_bytes, st);
+  if (d->dtype == DT_BF16) return launch_gemm<__bf16>(a, true, false, 1, d->workspace, d->workspace_bytes, st);
+  return -22;
+}
+
+extern "C" int hallo_set_option(const char* name, int value) {
+  if (!name) return -22;
+  if (!strcmp(name, "gemm_variant")) { if (value < 0 || value > 3) return -22; g_gemm_variant = value; return 0; }
+  if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }
   return -22;
 }

@@ -36,7 +36,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) { a[e] = 0.0f; q[e] = 0.0f; }
       const T* base = x + ((long)img * HW) * C + v * 8;
-      for (int r = r_begin + my_row; r < r_end; r += row_lanes) {
+      int r = r_begin + my_row;
+      // 4 independent 16-byte loads in flight per thread (the loop is latency-bound otherwise)
+      for (; r + 3 * row_lanes < r_end; r += 4 * row_lanes) {
+        V8 v0 = ld8<T>(base + (long)r * C);
+        V8 v1 = ld8<T>(base + (long)(r + row_lanes) * C);
+        V8 v2 = ld8<T>(base + (long)(r + 2 * row_lanes) * C);
+        V8 v3 = ld8<T>(base + (long)(r + 3 * row_lanes) * C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f0 = to_f32(v0[e]), f1 = to_f32(v1[e]), f2 = to_f32(v2[e]), f3 = to_f32(v3[e]);
+          a[e] += (f0 + f1) + (f2 + f3);
+          q[e] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+        }
+      }
+      for (; r < r_end; r += row_lanes) {
         V8 val = ld8<T>(base + (long)r * C);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float f = to_f32(val[e]); a[e] += f; q[e] += f * f; }
@@ -65,16 +79,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                        int nchunks, int rows_per_block, float eps, int silu) {
   using V8 = typename Vec<T>::v8;
   __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
+  __shared__ double s_part[8][GN_MAX_GROUPS][2];
   const int tid = threadIdx.x;
   const int img = blockIdx.y;
   const int cpg = C / groups;
+  {
+    // 8 partial sums per group in parallel, then one thread per group combines them (fp64)
+    const int g = tid & 31, part = tid >> 5;
+    double s = 0.0, q = 0.0;
+    if (g < groups) {
+      for (int c = part; c < nchunks; c += 8) {
+        const float* w = ws + (((long)img * nchunks + c) * groups + g) * 2;
+        s += (double)w[0];
+        q += (double)w[1];
+      }
+    }
+    s_part[part][g][0] = s;
+    s_part[part][g][1] = q;
+  }
+  __syncthreads();
   if (tid < groups) {
     double s = 0.0, q = 0.0;
-    for (int c = 0; c < nchunks; ++c) {
-      const float* w = ws + (((long)img * nchunks + c) * groups + tid) * 2;
-      s += (double)w[0];
-      q += (double)w[1];
-    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s += s_part[k][tid][0]; q += s_part[k][tid][1]; }
     const double n = (double)HW * cpg;
     const double mean = s / n;
     double var = q / n - mean * mean;
@@ -309,7 +336,7 @@ using namespace hallo;
 extern "C" int hallo_abi_version(void) { return 1; }
 
 extern "C" int hallo_groupnorm_chunks(int HW) {
-  int c = (HW + 255) / 256;
+  int c = (HW + 63) / 64;   // 64 rows per partial-statistics block: >= 1024 blocks at 16 x 64x64 frames
   if (c > 64) c = 64;
   if (c < 1) c = 1;
   return c;

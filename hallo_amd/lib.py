@@ -37,6 +37,8 @@ class GemmDesc(C.Structure):
         ("geglu", C.c_int),
         ("out_f32", C.c_int),
         ("dtype", C.c_int),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -56,6 +58,8 @@ class ConvDesc(C.Structure):
         ("alpha", C.c_float),
         ("act", C.c_int),
         ("dtype", C.c_int),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -78,6 +82,7 @@ class AttnDesc(C.Structure):
 # tests/test_abi.py checks that the built library exports each of them.
 SYMBOLS = {
     "hallo_abi_version": (C.c_int, []),
+    "hallo_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "hallo_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "hallo_conv3x3_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "hallo_attention": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),

@@ -36,6 +36,24 @@ def _chk_dev(*ts):
             raise _l.HalloLibraryError("hallo_amd operators need device (HIP) tensors; there is no CPU path")
 
 
+def set_option(name, value):
+    """Kernel A/B switch, e.g. set_option('gemm_variant', 0|1|2)."""
+    _l.check(_l.load().hallo_set_option(name.encode(), int(value)), f"hallo_set_option({name})")
+
+
+_splitk_ws = {}
+SPLITK_WS_BYTES = 128 << 20
+
+
+def _workspace(device):
+    """fp32 scratch for split-K partial sums: one fixed buffer per device (fixed address => hipGraph-safe)."""
+    ws = _splitk_ws.get(device)
+    if ws is None:
+        ws = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
+        _splitk_ws[device] = ws
+    return ws
+
+
 def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, act=ACT_NONE, geglu=False,
          bias2=None, bias2_rows_per_group=0, out_f32=False, bias_per_row=False):
     """out[M,N] = act(alpha * rowscale * (a[M,K] @ w[N,K]^T + bias) + residual).
@@ -70,6 +88,8 @@ def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, 
         d.residual, d.ldr = None, 0
     d.alpha, d.act, d.geglu, d.out_f32 = float(alpha), act, 1 if geglu else 0, 1 if out_f32 else 0
     d.dtype = dtype_code(a.dtype)
+    ws = _workspace(a.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), SPLITK_WS_BYTES
     _l.check(_l.load().hallo_gemm(C.byref(d), _stream()), "hallo_gemm")
     return out
 
@@ -90,6 +110,7 @@ def gemm_batched(a, w, out, *, out_f32=False, alpha=1.0, bias=None, bias_per_row
     d.bias2, d.bias2_rows_per_group, d.bias2_ld, d.rowscale, d.residual, d.ldr = None, 0, 0, None, None, 0
     d.alpha, d.act, d.geglu, d.out_f32 = float(alpha), ACT_NONE, 0, 1 if out_f32 else 0
     d.dtype = dtype_code(a.dtype)
+    d.workspace, d.workspace_bytes = None, 0
     _l.check(_l.load().hallo_gemm(C.byref(d), _stream()), "hallo_gemm(batched)")
     return out
 
@@ -124,6 +145,8 @@ def conv3x3(x, w, bias, n_img, H, W, *, stride=1, pad_t=1, pad_l=1, out_hw=None,
         d.residual, d.ldr = None, 0
     d.ldy = out.stride(-2)
     d.alpha, d.act, d.dtype = float(alpha), act, dtype_code(x.dtype)
+    ws = _workspace(x.device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), SPLITK_WS_BYTES
     _l.check(_l.load().hallo_conv3x3_nhwc(C.byref(d), _stream()), "hallo_conv3x3_nhwc")
     return out
 

@@ -33,6 +33,10 @@ extern "C" {
 
 int hallo_abi_version(void);
 
+/* Tuning / A-B switch (not part of the numerical contract): "gemm_variant" = 0 register-staged v1 kernel,
+ * 1 / 2 direct-to-LDS kernel with 1 / 2 LDS stages, 3 auto (default); "split_k" = 0 / 1 (auto, default).  Returns -22 for unknown names / values. */
+int hallo_set_option(const char* name, int value);
+
 /* ------------------------------------------------------------------------------------------
  * hallo_gemm: C[M,N] = act( alpha * rowscale[m] * (A[M,K] . W[N,K]^T + bias) + residual )
  * Replaces torch Linear / 1x1 Conv2d everywhere on the path:
@@ -66,6 +70,8 @@ typedef struct hallo_gemm_desc {
   int geglu;
   int out_f32;               /* write C as fp32 instead of dtype */
   int dtype;
+  void* workspace;           /* optional fp32 scratch for split-K partial sums (small grids with long K); may be null */
+  int64_t workspace_bytes;
 } hallo_gemm_desc;
 int hallo_gemm(const hallo_gemm_desc* d, void* stream);
 
@@ -94,6 +100,8 @@ typedef struct hallo_conv_desc {
   float alpha;
   int act;
   int dtype;
+  void* workspace;           /* optional split-K scratch, as in hallo_gemm_desc */
+  int64_t workspace_bytes;
 } hallo_conv_desc;
 int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream);
 
