@@ -269,7 +269,7 @@ __device__ uint4 g_zero_page[2];
 constexpr int TILE_ELEMS = 128 * 64;
 
 template <typename T, int MODE /*0 gemm, 1 conv3x3, 2 geglu*/, int STAGES>
-__global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 ? 3 : 4)) void gemm2_kernel(const GemmArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   constexpr bool CONV = MODE == 1, GEGLU = MODE == 2;
@@ -475,8 +475,20 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs p) {
       if (n < p.N) ld8f(bias + n, p.bias_vec_ok, bcol);
     }
   }
+  const bool use_res = !GEGLU && res && p.res_vec_ok && p.splits <= 1;
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
+    // residual rows of this half (4 row groups x 8 columns per lane): issued before the LDS transposition so
+    // that their latency overlaps it instead of serialising the read phase
+    V8 rpre[4];
+    if (use_res) {
+      const int n = n0 + wn * 64 + rc * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + tm * 32 + rr0 + 8 * i;
+        rpre[i] = (m < p.M && n < p.N) ? ld8<T>(res + (long)m * p.ldr + n) : zero8<T>();
+      }
+    }
     // ---- write phase: acc[tn][tm] -> tile[row = l31][col = tn*32 + 8g + 4hi + 0..3] ----
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
@@ -527,8 +539,11 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs p) {
           const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] *= rs;
-          if (res) {
-            ld8f(res + (long)m * p.ldr + n, p.res_vec_ok, t8);
+          if (use_res) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += to_f32(rpre[i][j]);
+          } else if (res) {
+            ld8f(res + (long)m * p.ldr + n, false, t8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += t8[j];
           }
@@ -629,7 +644,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
   if (v == 3) v = (tiles * batch >= 640) ? 1 : 2;
   a.splits = 1; a.nk_per_split = 0; a.slab = nullptr;
   const int nk = (a.K + BK - 1) / BK;
-  if (v != 0 && !geglu && batch == 1 && g_split_k && ws && tiles < 384 && nk >= 8) {
+  if (v != 0 && !geglu && batch == 1 && g_split_k && ws && tiles < 384 && nk >= 32) {
     // small grids with a long K loop (8x8 / 16x16 feature maps, K up to 23040): split K so that >= ~768 workgroups
     // are in flight; partial sums go to an fp32 slab and a second pass applies the epilogue in a fixed order
     int sp = (768 + tiles - 1) / tiles;
