@@ -48,7 +48,9 @@ class OpProfiler:
             r = fn(*a, **k)
             e.record()
             fl, by = cost(a, k, r)
-            self.records.append((name, s, e, fl, by))
+            shp = tuple(tuple(t.shape) for t in a[:3] if torch.is_tensor(t)) + ((("geglu",),) if k.get("geglu") else ()) \
+                + ((("res",),) if k.get("residual") is not None else ()) + ((("k2", tuple(k["k2"].shape)),) if k.get("k2") is not None else ())
+            self.records.append((name, s, e, fl, by, shp))
             return r
         return w
 
@@ -118,7 +120,15 @@ class OpProfiler:
     def summary(self):
         torch.cuda.synchronize()
         fam = {}
-        for name, s, e, fl, by in self.records:
+        self.by_shape = {}
+        for name, s, e, fl, by, shp in self.records:
+            d2 = self.by_shape.setdefault((name, shp), dict(ms=0.0, flop=0.0, bytes=0.0, launches=0))
+            ms_ = s.elapsed_time(e)
+            d2["ms"] += ms_
+            d2["flop"] += fl
+            d2["bytes"] += by
+            d2["launches"] += 1
+        for name, s, e, fl, by, shp in self.records:
             d = fam.setdefault(name, dict(ms=0.0, flop=0.0, bytes=0.0, launches=0))
             d["ms"] += s.elapsed_time(e)
             d["flop"] += fl
@@ -205,6 +215,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--shape-breakdown", action="store_true", help="write gpurun_out/shape_breakdown.json (per op x shape times)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -285,6 +296,14 @@ def main():
         run(inputs[-1])
         fam = prof.summary()
         prof.remove()
+        if args.shape_breakdown:
+            top = sorted(prof.by_shape.items(), key=lambda kv: -kv[1]["ms"])[:60]
+            rows = [dict(op=k[0], shapes=str(k[1]), ms=round(v["ms"], 2), launches=v["launches"],
+                         tflops=round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0,
+                         gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0) for k, v in top]
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "shape_breakdown.json"), "w") as f:
+                json.dump(rows, f, indent=1)
         tot_ms = sum(d["ms"] for d in fam.values())
         tot_flop = sum(d["flop"] for d in fam.values())
         out["kernels"] = {k: {"ms": round(d["ms"], 2), "launches": d["launches"], "tflops": round(d["tflops"], 1),

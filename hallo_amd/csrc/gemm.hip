@@ -49,6 +49,7 @@ struct GemmArgs {
   int vec_ok, res_vec_ok, bias_vec_ok, bias2_vec_ok;   // 8-byte (fp32: 16-byte) row accesses are aligned
   // conv gather
   int H, W, Cin, OH, OW, stride, pad_t, pad_l, upsample;
+  int conv_fast;   // Cin % 64 == 0 and no upsample: one tap per K tile, scalar tap offsets
 };
 
 template <typename T, bool CONV, bool GEGLU>
@@ -289,95 +290,160 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 ? 3 : 4)) void ge
 
   const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + zb * p.sA;
   const T* __restrict__ B = reinterpret_cast<const T*>(p.B) + zb * p.sB;
-  const T* zero = reinterpret_cast<const T*>(g_zero_page);
 
-  // ---- loader state: thread owns physical chunk lp of rows r_j = wave*32 + j*8 + lrow, j = 0..3 ----
+  // ---- loader: LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds) ----
+  // Thread owns physical chunk lp of rows r_j = wave*32 + j*8 + lrow (j = 0..3) of both operand tiles.  The per-lane
+  // byte offset of (row, swizzled chunk) is computed ONCE; the K advance is the instruction's SCALAR offset, so the
+  // steady-state K loop issues its 8 loads with no vector ALU work at all.  Rows past M / N, the K tail and the
+  // zero padding of the 3x3 gather use voffset = 0xFFFFFFFF: out of the descriptor's range -> the DMA writes zeros.
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int lrow = lane >> 3, lp = lane & 7;
   const int cA = lp ^ (lane >> 4);   // logical chunk of slabs j = 0, 2   ((r_j >> 1) & 7 == (lane >> 4) + 4*(j&1))
   const int cB = cA ^ 4;             // logical chunk of slabs j = 1, 3
+  auto clamp32 = [](long bytes) { return (int)(bytes > 0xFFFFFFFFL ? 0xFFFFFFFFL : bytes); };
 
-  const T* b_ptr[4];
+  const T* Bbase = GEGLU ? B : B + (long)n0 * p.ldb;
+  const long b_rows = GEGLU ? 2L * p.N : (long)(p.N - n0);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(Bbase), 0, clamp32(((b_rows - 1) * p.ldb + p.K) * 2), 0x00020000);
+  unsigned b_voff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = wave * 32 + j * 8 + lrow;
-    int wrow;
+    const int c = (j & 1) ? cB : cA;
+    long wrow;
+    bool ok;
     if (GEGLU) {
-      const int jw = r >> 6, t = (r >> 5) & 1, c = r & 31;   // tile rows: [wn(2)][value, gate][32]
-      int col = n0 + jw * 32 + c;
-      col = col < p.N ? col : p.N - 1;
-      wrow = t * p.N + col;
+      const int jw = r >> 6, t = (r >> 5) & 1, cc = r & 31;   // tile rows: [wn(2)][value, gate][32]
+      const int col = n0 + jw * 32 + cc;
+      ok = col < p.N;
+      wrow = (long)t * p.N + col;
     } else {
-      wrow = n0 + r;
-      wrow = wrow < p.N ? wrow : p.N - 1;
+      ok = n0 + r < p.N;
+      wrow = r;
     }
-    b_ptr[j] = B + (long)wrow * p.ldb;
+    b_voff[j] = ok ? (unsigned)((wrow * p.ldb + c * 8) * 2) : OOB;
   }
-  const T* a_ptr[4];
-  int a_iy[4], a_ix[4];
+
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kt_begin = (p.splits > 1) ? blockIdx.y * p.nk_per_split : 0;
+  const int kt_end = (p.splits > 1) ? min(nk_all, kt_begin + p.nk_per_split) : nk_all;
+
+  unsigned a_voff[4];
+  unsigned a_mask[4] = {0, 0, 0, 0};     // conv fast path: bit t set <=> tap t of this row is inside the image
+  int a_iy[4] = {0, 0, 0, 0}, a_ix[4] = {0, 0, 0, 0};
+  const T* Abase;
+  long a_bytes;
+  const int VH = CONV ? (p.upsample ? 2 * p.H : p.H) : 0;
+  const int VW = CONV ? (p.upsample ? 2 * p.W : p.W) : 0;
+  const bool cfast = CONV && p.conv_fast;
+  if (CONV) {
+    const int hw = p.OH * p.OW;
+    const int img0 = m0 / hw, n_img = p.M / hw;
+    const long img_elems = (long)p.H * p.W * p.Cin;
+    const long shift = cfast ? ((long)p.pad_t * p.W + p.pad_l) * p.Cin : 0;   // taps are addressed from (-pad_t, -pad_l)
+    Abase = A + img0 * img_elems - shift;
+    a_bytes = ((long)(n_img - img0) * img_elems + shift) * 2;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int m = m0 + wave * 32 + j * 8 + lrow;
-    if (m >= p.M) m = p.M - 1;
-    if (CONV) {
-      const int hw = p.OH * p.OW;
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wave * 32 + j * 8 + lrow;
+      const int c = (j & 1) ? cB : cA;
       const int img = m / hw, rem = m - img * hw;
       const int oy = rem / p.OW, ox = rem - oy * p.OW;
       a_iy[j] = oy * p.stride - p.pad_t;
       a_ix[j] = ox * p.stride - p.pad_l;
-      a_ptr[j] = A + (long)img * p.H * p.W * p.Cin;
-    } else {
-      a_ptr[j] = A + (long)m * p.lda;
-      a_iy[j] = a_ix[j] = 0;
+      const unsigned img_off = (unsigned)((img - img0) * img_elems * 2);
+      if (cfast) {
+        a_voff[j] = (m < p.M) ? img_off + (unsigned)((((long)oy * p.stride * p.W + ox * p.stride) * p.Cin + c * 8) * 2) : OOB;
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int vy = a_iy[j] + t / 3, vx = a_ix[j] + t % 3;
+          if (m < p.M && vy >= 0 && vy < p.H && vx >= 0 && vx < p.W) mk |= 1u << t;
+        }
+        a_mask[j] = mk;
+      } else {
+        a_voff[j] = (m < p.M) ? img_off : OOB;     // image base only; the pixel / channel part is per K tile
+      }
+    }
+  } else {
+    Abase = A + (long)m0 * p.lda;
+    const int rows = min(p.M - m0, BM);
+    a_bytes = ((long)(rows - 1) * p.lda + p.K) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = wave * 32 + j * 8 + lrow;
+      const int c = (j & 1) ? cB : cA;
+      a_voff[j] = (r < rows) ? (unsigned)(((long)r * p.lda + c * 8) * 2) : OOB;
     }
   }
-  // conv: (tap, channel) of this thread's two logical chunks in the current K tile
-  const int nk_all = (p.K + BK - 1) / BK;
-  const int kt_begin = (p.splits > 1) ? blockIdx.y * p.nk_per_split : 0;
-  const int kt_end = (p.splits > 1) ? min(nk_all, kt_begin + p.nk_per_split) : nk_all;
-  int tapA = 0, chA = 0, tapB = 0, chB = 0;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Abase), 0, clamp32(a_bytes), 0x00020000);
+
+  // conv K position.  Fast path (Cin % 64 == 0): one tap per K tile, tracked in scalars.  General path: the two
+  // logical chunks of a thread may sit in different taps; tracked per thread.
+  int tap_u = 0, ch_u = 0, tapA = 0, chA = 0, tapB = 0, chB = 0;
   if (CONV) {
     const int k0 = kt_begin * BK;
+    tap_u = k0 / p.Cin; ch_u = k0 - tap_u * p.Cin;
     tapA = (k0 + cA * 8) / p.Cin; chA = k0 + cA * 8 - tapA * p.Cin;
     tapB = (k0 + cB * 8) / p.Cin; chB = k0 + cB * 8 - tapB * p.Cin;
   }
-  const int VH = CONV ? (p.upsample ? 2 * p.H : p.H) : 0;
-  const int VW = CONV ? (p.upsample ? 2 * p.W : p.W) : 0;
+
+#define HALLO_BLOAD(rs, ldsptr, voff, soff) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ldsptr), 16, (int)(voff), (int)(soff), 0, 0)
 
   auto stage = [&](int kt, int buf) {
-    T* sA = smem + buf * 2 * TILE_ELEMS;
+    T* sA = smem + buf * 2 * TILE_ELEMS + wave_u * 32 * BK;
     T* sB = sA + TILE_ELEMS;
-    const int kA = kt * BK + cA * 8, kB = kt * BK + cB * 8;
-    int kyA = 0, kxA = 0, kyB = 0, kxB = 0;
-    if (CONV) {
-      kyA = tapA / 3; kxA = tapA - kyA * 3;
-      kyB = tapB / 3; kxB = tapB - kyB * 3;
-    }
+    const bool tail = (kt + 1) * BK > p.K;        // wave-uniform; only the last tile of a K % 64 != 0 problem
+    const int soff = kt * BK * 2;
+    if (!tail) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int kk = (j & 1) ? kB : kA;
-      const bool kin = kk < p.K;
-      const T* sb = kin ? b_ptr[j] + kk : zero;
-      const T* sa;
-      if (CONV) {
+      for (int j = 0; j < 4; ++j) HALLO_BLOAD(rsB, sB + j * 8 * BK, b_voff[j], soff);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = kt * BK + ((j & 1) ? cB : cA) * 8;
+        HALLO_BLOAD(rsB, sB + j * 8 * BK, (kk < p.K && b_voff[j] != OOB) ? b_voff[j] + soff : OOB, 0);
+      }
+    }
+    if (!CONV) {
+      if (!tail) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) HALLO_BLOAD(rsA, sA + j * 8 * BK, a_voff[j], soff);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kk = kt * BK + ((j & 1) ? cB : cA) * 8;
+          HALLO_BLOAD(rsA, sA + j * 8 * BK, (kk < p.K && a_voff[j] != OOB) ? a_voff[j] + soff : OOB, 0);
+        }
+      }
+    } else if (cfast) {
+      const int ky = tap_u / 3, kx = tap_u - ky * 3;
+      const int soffA = ((ky * p.W + kx) * p.Cin + ch_u) * 2;
+      const unsigned bit = 1u << tap_u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) HALLO_BLOAD(rsA, sA + j * 8 * BK, (a_mask[j] & bit) ? a_voff[j] : OOB, soffA);
+      ch_u += BK;
+      if (ch_u >= p.Cin) { ch_u = 0; ++tap_u; }
+    } else {
+      const int kA = kt * BK + cA * 8, kB = kt * BK + cB * 8;
+      const int kyA = tapA / 3, kxA = tapA - kyA * 3, kyB = tapB / 3, kxB = tapB - kyB * 3;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = (j & 1) ? kB : kA;
         const int ky = (j & 1) ? kyB : kyA, kx = (j & 1) ? kxB : kxA, ch = (j & 1) ? chB : chA;
         const int vy = a_iy[j] + ky, vx = a_ix[j] + kx;
-        const bool inb = kin && vy >= 0 && vy < VH && vx >= 0 && vx < VW;
+        const bool inb = kk < p.K && a_voff[j] != OOB && vy >= 0 && vy < VH && vx >= 0 && vx < VW;
         const int sy = p.upsample ? (vy >> 1) : vy, sx = p.upsample ? (vx >> 1) : vx;
-        sa = inb ? a_ptr[j] + ((long)sy * p.W + sx) * p.Cin + ch : zero;
-      } else {
-        sa = kin ? a_ptr[j] + kk : zero;
+        HALLO_BLOAD(rsA, sA + j * 8 * BK, inb ? a_voff[j] + (unsigned)(((sy * p.W + sx) * p.Cin + ch) * 2) : OOB, 0);
       }
-      const int slab = (wave * 32 + j * 8) * BK;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
-                                       (__attribute__((address_space(3))) void*)(sA + slab), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
-                                       (__attribute__((address_space(3))) void*)(sB + slab), 16, 0, 0);
-    }
-    if (CONV) {
       chA += BK; while (chA >= p.Cin) { chA -= p.Cin; ++tapA; }
       chB += BK; while (chB >= p.Cin) { chB -= p.Cin; ++tapB; }
     }
   };
+#undef HALLO_BLOAD
 
   f32x16 acc[2][2];   // [tn][tm]
 #pragma unroll
@@ -633,6 +699,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 
 static int g_gemm_variant = 3;   // 0: v1 (register-staged), 1 / 2: v2 with 1 / 2 LDS stages, 3: auto (1 or 2 by grid size)
 static int g_split_k = 1;        // 0: never split K, 1: auto
+static int g_conv_fast = 1;      // 0: always use the general (per-thread tap) conv gather
 
 
 template <typename T>
@@ -714,6 +781,7 @@ extern "C" int hallo_gemm(const hallo_gemm_desc* d, void* stream) {
   a.tiles_m = (d->M + BM - 1) / BM;
   a.tiles_n = d->geglu ? (d->N + 63) / 64 : (d->N + BN - 1) / BN;
   a.H = a.W = a.Cin = a.OH = a.OW = a.stride = a.pad_t = a.pad_l = a.upsample = 0;
+  a.conv_fast = 0;
   set_vec_flags(a, d->out_f32 ? 4 : 2);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == DT_F16) return launch_gemm<_Float16>(a, false, d->geglu != 0, d->batch, d->workspace, d->workspace_bytes, st);
@@ -741,6 +809,7 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
   a.tiles_n = (a.N + BN - 1) / BN;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW;
   a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.upsample = d->upsample;
+  a.conv_fast = (d->Cin % 64 == 0) && !d->upsample && g_conv_fast;
   set_vec_flags(a, 2);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == DT_F16) return launch_gemm<_Float16>(a, true, false, 1, d->workspace, d->workspace_bytes, st);
@@ -751,6 +820,7 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
 extern "C" int hallo_set_option(const char* name, int value) {
   if (!name) return -22;
   if (!strcmp(name, "gemm_variant")) { if (value < 0 || value > 3) return -22; g_gemm_variant = value; return 0; }
+  if (!strcmp(name, "conv_fast")) { if (value < 0 || value > 1) return -22; g_conv_fast = value; return 0; }
   if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }
   return -22;
 }
