@@ -235,7 +235,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     pipe, audioproj = build_pipeline(dev, dtype)
     S, Fr = args.size, args.frames
-    gathered = torch.empty((world, Fr, 3, S * S), device=dev, dtype=torch.float32) if world > 1 else None
+    from hallo_amd.animate.clip_parallel import gather_wave
     host = torch.empty((Fr, 3, S * S), dtype=torch.float32).pin_memory()
 
     def one_clip(idx):
@@ -251,9 +251,9 @@ def main():
         lat = lat[0].permute(1, 2, 3, 0).reshape(Fr * h * h, 4).contiguous()
         frames, _, _ = pipe.decode_latents_device(lat, Fr, h, h)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, frames)      # decoded frames of all clips, clip order = rank
+            g = gather_wave(frames)                            # RCCL all-gather of decoded frames, clip order = rank
             if rank == 0:
-                host.copy_(gathered[0], non_blocking=True)
+                host.copy_(g[0], non_blocking=True)
         else:
             host.copy_(frames, non_blocking=True)
         return frames

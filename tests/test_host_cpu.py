@@ -1,0 +1,97 @@
+"""CPU tests of the host side: drop-in surface (state-dict key names / shapes identical to the reference
+architecture as restated by the oracle), plugin surface, error behaviour, no-fallback guarantees."""
+import pytest
+import torch
+
+from oracle import hallo_ref as H
+from oracle import harness as Hn
+
+
+def _keys(m):
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+
+def test_state_dict_contract_full_size():
+    """Full SD-1.5 widths on the meta device: 1946 / 682 entries with identical names+shapes."""
+    from hallo_amd.models.unet_2d_condition import UNet2DConditionModel
+    from hallo_amd.models.unet_3d import UNet3DConditionModel
+    with torch.device("meta"):
+        n3, o3 = UNet3DConditionModel(), H.UNet3DConditionModel()
+        n2, o2 = UNet2DConditionModel(), H.UNet2DConditionModel()
+    assert _keys(n3) == _keys(o3) and len(_keys(n3)) == 1946
+    assert _keys(n2) == _keys(o2) and len(_keys(n2)) == 682
+    assert sum(p.numel() for p in n3.parameters()) == sum(p.numel() for p in o3.parameters())
+
+
+def test_state_dict_contract_small_modules():
+    from diffusers import AutoencoderKL as OVAE
+    from hallo_amd.models.audio_proj import AudioProjModel
+    from hallo_amd.models.face_locator import FaceLocator
+    from hallo_amd.models.image_proj import ImageProjModel
+    from hallo_amd.models.vae import AutoencoderKL
+    with torch.device("meta"):
+        pairs = [(AutoencoderKL(), OVAE()), (FaceLocator(320), H.FaceLocator(320)),
+                 (ImageProjModel(768, 512, 4), H.ImageProjModel(768, 512, 4)), (AudioProjModel(), H.AudioProjModel())]
+    for a, b in pairs:
+        assert _keys(a) == _keys(b)
+
+
+def test_plugin_surface():
+    from hallo_amd.models.unet_3d import HalloHipAttnProcessor, UNet3DConditionModel
+    with torch.device("meta"):
+        m = UNet3DConditionModel(**Hn.SMALL, audio_attention_dim=48, motion_module_kwargs=Hn.SMALL_MM)
+    procs = m.attn_processors
+    # 16 spatial blocks x (attn1, attn2) + 16 audio blocks x (attn1 + 3 cross) ; temporal transformers excluded
+    assert len(procs) == 16 * 2 + 16 * 4 and all("temporal_transformer" not in k for k in procs)
+    m.set_attn_processor(HalloHipAttnProcessor())
+    m.set_attention_slice("auto")
+    with pytest.raises(ValueError):
+        m.set_attn_processor(object())            # no PyTorch / xformers fallback on this path
+    with pytest.raises(ValueError):
+        m.set_attn_processor({"x": HalloHipAttnProcessor()})
+    assert m.enable_gradient_checkpointing() is None and m.config.cross_attention_dim == 64 and m.in_channels == 4
+
+
+def test_unsupported_configurations_raise():
+    from hallo_amd.models.unet_3d import UNet3DConditionModel
+    with pytest.raises(ValueError):
+        UNet3DConditionModel(use_motion_module=False)
+    with pytest.raises(ValueError):
+        UNet3DConditionModel(down_block_types=("DownBlock3D",) * 4)
+
+
+def test_no_cpu_fallback():
+    """CPU tensors / missing library fail loudly instead of silently computing somewhere else."""
+    from hallo_amd import lib, ops
+    from hallo_amd.models.image_proj import ImageProjModel
+    with pytest.raises(lib.HalloLibraryError):
+        ops.gemm(torch.zeros(8, 8, dtype=torch.float16), torch.zeros(8, 8, dtype=torch.float16))
+    m = ImageProjModel(64, 512, 4)
+    with pytest.raises(lib.HalloLibraryError):
+        m.prepare()
+    with pytest.raises(lib.HalloLibraryError):
+        lib.load("/nonexistent/libhallo_amd.so")
+    with pytest.raises(TypeError):
+        ops.dtype_code(torch.float32)
+
+
+def test_reference_control_contract():
+    from hallo_amd.models.mutual_self_attention import ReferenceAttentionControl
+    from hallo_amd.models.unet_2d_condition import UNet2DConditionModel
+    from hallo_amd.models.unet_3d import UNet3DConditionModel
+    with torch.device("meta"):
+        den = UNet3DConditionModel(**Hn.SMALL, audio_attention_dim=48, motion_module_kwargs=Hn.SMALL_MM)
+        ref = UNet2DConditionModel(**Hn.SMALL)
+    w = ReferenceAttentionControl(ref, mode="write", fusion_blocks="full")
+    r = ReferenceAttentionControl(den, mode="read", do_classifier_free_guidance=True, fusion_blocks="full")
+    assert den.reference_do_cfg is True
+    with pytest.raises(RuntimeError):
+        r.update(w)                               # writer has not run
+    ref.written_banks = [torch.ones(6, 4, 8) * 1.0001 for _ in range(16)]
+    r.update(w)
+    assert len(den.reference_bank) == 16 and den.reference_bank[0].dtype == torch.float16   # F4: always fp16
+    r.clear()
+    w.clear()
+    assert den.reference_bank is None and ref.written_banks == []
+    with pytest.raises(AssertionError):
+        ReferenceAttentionControl(den, mode="bogus")
