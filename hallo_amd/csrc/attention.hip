@@ -34,7 +34,7 @@ struct AttnArgs {
 };
 
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, HD <= 80 ? 2 : 1) void attn_kernel(const AttnArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   constexpr int KVB = (HD > 80) ? 32 : 64;       // kv rows per tile
@@ -47,9 +47,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
   constexpr int VT_LD = KVB + 4;                 // LDS row pitch of V^T (elements)
   constexpr int KU = (KVB * NCH + 255) / 256;    // K loader units per thread
   constexpr int VU = ((KVB / 2) * NCH + 255) / 256;  // V loader units (kv pairs) per thread
+  // Row sums for free: when the padded O^T block has a spare row (hd 40 -> 64 rows, 80 -> 96), V^T row HD is set to
+  // all ones, so the PV MFMA accumulates sum_kv P into O^T[HD][q] -- rescaled together with O, no VALU adds.
+  constexpr bool ONES_ROW = (NDB * 32 > HD);
+  constexpr int L_DB = HD / 32, L_R = ((HD % 32) / 8) * 4 + (HD % 4);   // accumulator slot of row HD (lanes hi = 0); HD % 8 == 0
 
-  __shared__ __attribute__((aligned(16))) T sK[KVB * K_LD];
-  __shared__ __attribute__((aligned(16))) T sVT[NDB * 32 * VT_LD];
+  // two LDS stages for K and V^T: tile it+1 is written into the other stage while tile it is consumed, so the
+  // K/V loop needs ONE barrier per tile (global loads of tile it+1 are in flight under the MFMAs of tile it)
+  constexpr int SK_ELEMS = KVB * K_LD, SVT_ELEMS = NDB * 32 * VT_LD;
+  __shared__ __attribute__((aligned(16))) T smem_kv[2 * (SK_ELEMS + SVT_ELEMS)];
+  T* const sK0 = smem_kv;
+  T* const sVT0 = smem_kv + 2 * SK_ELEMS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
@@ -72,7 +80,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 
   // zero the K pad columns (HD..HDP-1) once; the loaders never touch them
   if (HDP > HD) {
-    for (int r = tid; r < KVB; r += 256) st8<T>(&sK[r * K_LD + NCH * 8], zero8<T>());
+    for (int r = tid; r < 2 * KVB; r += 256) st8<T>(&sK0[r * K_LD + NCH * 8], zero8<T>());   // both stages (contiguous)
+  }
+
+  if (ONES_ROW) {
+    for (int c = tid; c < 2 * VT_LD; c += 256)
+      sVT0[(c / VT_LD) * SVT_ELEMS + HD * VT_LD + (c % VT_LD)] = from_f32<T>(1.0f);
   }
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q0 + l31][ks*16 + hi*8 .. +8] ----
@@ -118,7 +131,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
       }
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int stage) {
+    T* sK = sK0 + stage * SK_ELEMS;
+    T* sVT = sVT0 + stage * SVT_ELEMS;
 #pragma unroll
     for (int i = 0; i < KU; ++i) {
       const int u = tid + 256 * i;
@@ -155,23 +170,24 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 
   if (nt > 0) {
     load_tile(0);
-    store_tile();
+    store_tile(0);
   }
   __syncthreads();
 
   for (int it = 0; it < nt; ++it) {
     if (it + 1 < nt) load_tile(it + 1);
+    const T* sK = sK0 + (it & 1) * SK_ELEMS;
+    const T* sVT = sVT0 + (it & 1) * SVT_ELEMS;
 
     // ---- S^T = K . Q^T ----
     f32x16 s[NT];
+    const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = 0.0f;
-#pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         V8 kf = ld8<T>(&sK[(t * 32 + l31) * K_LD + ks * 16 + hi * 8]);
-        s[t] = Vec<T>::mfma32(kf, qf[ks], s[t]);
+        s[t] = Vec<T>::mfma32(kf, qf[ks], ks == 0 ? zero16 : s[t]);   // C = inline 0 on the first k-step
       }
     }
 
@@ -202,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
-      l_run *= alpha;
+      if (!ONES_ROW) l_run *= alpha;
 #pragma unroll
       for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -215,11 +231,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], p.scale_log2e, -m_run));
-        psum += pv;
+        if (!ONES_ROW) psum += pv;
         pf[t][r >> 3][r & 7] = from_f32<T>(pv);
       }
     }
-    l_run += psum;
+    if (!ONES_ROW) l_run += psum;
 
     // ---- O^T += V^T . P^T ----
 #pragma unroll
@@ -240,15 +256,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
       }
     }
 
+    if (it + 1 < nt) store_tile((it + 1) & 1);   // other stage: last read in iteration it-1, behind that iteration's barrier
     __syncthreads();
-    if (it + 1 < nt) {
-      store_tile();
-      __syncthreads();
-    }
   }
 
   // ---- normalise and store: lane owns row q0+l31, d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot;
+  if (ONES_ROW) l_tot = __shfl(oacc[L_DB][L_R], l31, 64);       // row HD of O^T lives in the hi = 0 lane of column q
+  else l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
   if (q0 + l31 < p.Lq) {
     T* orow = Og + (long)(q0 + l31) * p.o_rs;
@@ -295,15 +310,15 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
   using V8 = typename Vec<T>::v8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int Wd = hpb * hd;                    // channels handled by this block
-  T* sQKV = reinterpret_cast<T*>(smem_raw);   // [F][3][Wd]
-  float* sP = reinterpret_cast<float*>(smem_raw + (size_t)F * 3 * Wd * sizeof(T));  // [hpb][F][F+1]
+  const int W3 = 3 * Wd + 8;                  // frame pitch: +16 B so that the per-frame rows fall on distinct bank groups
+  T* sQKV = reinterpret_cast<T*>(smem_raw);   // [F][3*Wd + 8]
+  float* sP = reinterpret_cast<float*>(smem_raw + (size_t)F * W3 * sizeof(T));  // [hpb][F][F+1]
 
   const int tid = threadIdx.x;
   const int pix = blockIdx.x % HW, b = blockIdx.x / HW;
   const int cbase = blockIdx.y * Wd;          // first channel of this head group
   const long C3 = 3L * C;
   const int vpp = Wd / 8;                     // 16-byte vectors per part
-  const int W3 = 3 * Wd;
 
   for (int u = tid; u < F * 3 * vpp; u += 256) {
     const int f = u / (3 * vpp), rem = u - f * 3 * vpp;
@@ -321,11 +336,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
     const T* qp = &sQKV[i * W3 + hh * hd];
     const T* kp = &sQKV[j * W3 + Wd + hh * hd];
     float acc = 0.0f;
-    for (int d = 0; d < hd; d += 8) {
-      V8 a = ld8<T>(qp + d), k = ld8<T>(kp + d);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += to_f32(a[e]) * to_f32(k[e]);
-    }
+    for (int d = 0; d < hd; d += 8) acc = dot8<V8>(ld8<T>(qp + d), ld8<T>(kp + d), acc);
     sP[(hh * F + i) * FP + j] = acc * scale_log2e;
   }
   __syncthreads();
@@ -394,7 +405,7 @@ extern "C" int hallo_temporal_attention(const void* qkv, void* out, int B, int F
   const int hd = C / heads;
   // heads per block: largest divisor of `heads` whose slab fits ~40 KB (>= 4 workgroups per CU)
   int hpb = heads;
-  auto lds_for = [&](int g) { return (size_t)F * 3 * g * hd * 2 + (size_t)g * F * (F + 1) * sizeof(float); };
+  auto lds_for = [&](int g) { return (size_t)F * (3 * g * hd + 8) * 2 + (size_t)g * F * (F + 1) * sizeof(float); };
   while (hpb > 1 && (lds_for(hpb) > 40 * 1024 || heads % hpb)) --hpb;
   const size_t lds = lds_for(hpb);
   if (lds > 64 * 1024) return -22;

@@ -35,6 +35,20 @@ template <> struct Vec<__bf16> {
   }
 };
 
+// packed 2-element dot product with fp32 accumulate (v_dot2c_f32_f16 / v_dot2c_f32_bf16): no conversions needed
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+__device__ __forceinline__ float dot2(f16x2 a, f16x2 b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+__device__ __forceinline__ float dot2(bf16x2 a, bf16x2 b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
+// 8-element dot product of two 16-byte vectors
+template <typename V8> __device__ __forceinline__ float dot8(V8 a, V8 b, float c) {
+  c = dot2(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), c);
+  c = dot2(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), c);
+  c = dot2(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), c);
+  c = dot2(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), c);
+  return c;
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return static_cast<float>(x); }
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return static_cast<T>(x); }
 

@@ -55,12 +55,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float f = to_f32(val[e]); a[e] += f; q[e] += f * f; }
       }
+      // the 8 channels of a vector are consecutive: runs of equal group index are combined before the LDS atomics
+      int g_run = (v * 8) / cpg;
+      float sa = 0.0f, sq = 0.0f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int g = (v * 8 + e) / cpg;
-        atomicAdd(&s_sum[g], a[e]);
-        atomicAdd(&s_sq[g], q[e]);
+        if (g != g_run) {
+          atomicAdd(&s_sum[g_run], sa);
+          atomicAdd(&s_sq[g_run], sq);
+          sa = 0.0f; sq = 0.0f; g_run = g;
+        }
+        sa += a[e];
+        sq += q[e];
       }
+      atomicAdd(&s_sum[g_run], sa);
+      atomicAdd(&s_sq[g_run], sq);
     }
   }
   __syncthreads();
@@ -110,27 +120,39 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
+  // thread -> (row lane, channel vector): gamma/beta/mean/rstd of a vector are folded into y = x * sc + sh ONCE,
+  // the row loop is load, 8 FMA (+SiLU), store
   const int vpr = C / 8;
+  const int tpr = vpr <= 256 ? vpr : 256;
+  const int row_lanes = 256 / tpr;
+  const int my_row = tid / tpr, my_v0 = tid % tpr;
   const long r_begin = (long)blockIdx.x * rows_per_block;
   const long r_end = min((long)HW, r_begin + rows_per_block);
-  const long total = (r_end - r_begin) * vpr;
-  const T* xb = x + ((long)img * HW + r_begin) * C;
-  T* yb = y + ((long)img * HW + r_begin) * C;
-  for (long u = tid; u < total; u += 256) {
-    const int v = (int)(u % vpr);
-    const int c0 = v * 8;
-    V8 val = ld8<T>(xb + u * 8);
-    V8 g8 = ld8<T>(gamma + c0), b8 = ld8<T>(beta + c0);
-    V8 o;
+  if (my_row < row_lanes) {
+    for (int v = my_v0; v < vpr; v += tpr) {
+      const int c0 = v * 8;
+      V8 g8 = ld8<T>(gamma + c0), b8 = ld8<T>(beta + c0);
+      float sc[8], sh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int g = (c0 + e) / cpg;
-      float f = (to_f32(val[e]) - s_mean[g]) * s_rstd[g];
-      f = f * to_f32(g8[e]) + to_f32(b8[e]);
-      if (silu) f = silu_f(f);
-      o[e] = from_f32<T>(f);
+      for (int e = 0; e < 8; ++e) {
+        const int g = (c0 + e) / cpg;
+        sc[e] = s_rstd[g] * to_f32(g8[e]);
+        sh[e] = to_f32(b8[e]) - s_mean[g] * sc[e];
+      }
+      const T* xb = x + ((long)img * HW) * C + c0;
+      T* yb = y + ((long)img * HW) * C + c0;
+      for (long r = r_begin + my_row; r < r_end; r += row_lanes) {
+        V8 val = ld8<T>(xb + r * C);
+        V8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float f = __builtin_fmaf(to_f32(val[e]), sc[e], sh[e]);
+          if (silu) f = silu_f(f);
+          o[e] = from_f32<T>(f);
+        }
+        st8<T>(yb + r * C, o);
+      }
     }
-    st8<T>(yb + u * 8, o);
   }
 }
 
@@ -180,13 +202,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     const int vi = lane + 64 * i;
     if (vi < vpr) {
       V8 g8 = ld8<T>(gamma + vi * 8), b8 = ld8<T>(beta + vi * 8);
+      float pe8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (per) {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(per + vi * 8), p1 = *reinterpret_cast<const f32x4*>(per + vi * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pe8[e] = p0[e]; pe8[4 + e] = p1[e]; }
+      }
       V8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float f = (v[i][e] - mean) * rstd * to_f32(g8[e]) + to_f32(b8[e]);
         if (per) {
           // the reference adds the PE to the already-rounded LayerNorm output (motion_module.py:459)
-          f = to_f32(from_f32<T>(f)) + per[vi * 8 + e];
+          f = to_f32(from_f32<T>(f)) + pe8[e];
         }
         o[e] = from_f32<T>(f);
       }
