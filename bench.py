@@ -141,33 +141,50 @@ class OpProfiler:
 
 
 # ------------------------------------------------------------------------------------------------
-# CPU baseline: the oracle (plain PyTorch restatement of the reference) on this box's host cores
+# CPU baseline: the oracle (plain PyTorch restatement of the reference) on this box's host cores.
+# Runs in a child process under a hard wall-clock limit so that the GPU number can never be lost to it;
+# the child prints one JSON line per completed sample (coarse first, better ones after) and the parent
+# keeps the last one it saw.
 # ------------------------------------------------------------------------------------------------
-def cpu_baseline(frames, steps_ddim, budget_s=30.0):
+# TFLOP per UNet3D forward at B = 1 (BASELINE.md section 2 accounting): size -> TFLOP
+UNET_TFLOP = {(128, 4): 0.351, (256, 8): 2.74, (512, 16): 25.59}
+
+
+def usable_cores():
+    """Threads this process may actually run on: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))     # more threads than that only adds fork/join overhead to the oracle's small ops
+
+
+def cpu_baseline_worker(frames, steps_ddim, budget_s):
+    """Child process body.  Sample ladder: one full-width UNet3D forward at 128^2 x 4f, then 256^2 x 8f, then
+    (if the projected time fits the budget) 512^2 x 16f; each is scaled to the 512^2 x 16f forward by the FLOP
+    ratio and to a clip as steps x forward + VAE / ReferenceNet by FLOP ratio."""
+    t_start = time.time()
     from oracle import hallo_ref as H
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
-    t0 = time.time()
     with torch.device("meta"):
         den = H.UNet3DConditionModel()
-        ref = H.UNet2DConditionModel()
+    den.to_empty(device="cpu")
     chunk = torch.randn(1 << 22) * 0.02
-
-    def fill(m):
-        m.to_empty(device="cpu")
-        with torch.no_grad():
-            for name, p in list(m.named_parameters()) + list(m.named_buffers()):
-                flat = p.view(-1)
-                if "norm" in name and name.endswith("weight") and p.dim() == 1:
-                    flat.fill_(1.0)
-                    continue
-                for o in range(0, flat.numel(), chunk.numel()):
-                    n = min(chunk.numel(), flat.numel() - o)
-                    flat[o:o + n] = chunk[:n]
-        return m.eval()
-    den, ref = fill(den), fill(ref)
-    # PE buffers were overwritten by fill(); irrelevant for timing
-    build_s = time.time() - t0
+    with torch.no_grad():
+        for name, p in list(den.named_parameters()) + list(den.named_buffers()):
+            flat = p.view(-1)
+            if "norm" in name and name.endswith("weight") and p.dim() == 1:
+                flat.fill_(1.0)
+                continue
+            for o in range(0, flat.numel(), chunk.numel()):
+                n = min(chunk.numel(), flat.numel() - o)
+                flat[o:o + n] = chunk[:n]
+    den.eval()
+    build_s = time.time() - t_start
 
     def unet_time(S, Fr):
         h = S // 8
@@ -177,29 +194,64 @@ def cpu_baseline(frames, steps_ddim, budget_s=30.0):
         audio = torch.randn((1, Fr, 32, 768), generator=g)
         fm = torch.randn((1, 320, Fr, h, h), generator=g)
         mk = lambda: [torch.rand((Fr, (h // 2 ** l) ** 2), generator=g) for l in range(4)]
+        # the 16 reference-feature banks (what the ReferenceNet write pass would produce), fp16 like the reference
+        dims = [320] * 2 + [640] * 2 + [1280] * 2 + [1280] + [1280] * 3 + [640] * 3 + [320] * 3
+        lv = [0, 0, 1, 1, 2, 2, 3, 2, 2, 2, 1, 1, 1, 0, 0, 0]
+        banks = [torch.randn((3, (h // 2 ** l) ** 2, c), generator=g).to(torch.float16) for c, l in zip(dims, lv)]
         with torch.no_grad():
-            t = time.time()
-            banks = [b.to(torch.float16) for b in ref(torch.randn((3, 4, h, h), generator=g), torch.tensor(0), enc)]
-            t_ref = time.time() - t
             t = time.time()
             den(lat, torch.tensor(500), enc, banks, audio_embedding=audio, mask_cond_fea=fm, full_mask=mk(),
                 face_mask=mk(), lip_mask=mk(), motion_scale=[1.0, 1.0, 1.0])
-            return time.time() - t, t_ref
-    # TFLOP per UNet3D forward: 2.74 @256^2 x 8f, 25.59 @512^2 x 16f (B = 1)
-    t_small, _ = unet_time(256, 8)
-    if t_small * (25.59 / 2.74) <= budget_s:
-        t_unet, t_ref = unet_time(512, 16)
-        sample = "1 UNet3D forward + ReferenceNet write at 512x512x16f (B=1, fp32), measured"
-    else:
-        t_unet, t_ref = t_small * (25.59 / 2.74), None
-        sample = ("1 UNet3D forward at 256x256x8f (B=1, fp32) = %.1f s, scaled by the FLOP ratio 25.59/2.74 to "
-                  "512x512x16f" % t_small)
-    rate = 25.59 / t_unet                                   # achieved CPU TFLOP/s on the UNet
-    other = (frames * 2.515 + 3 * 1.117 + 2.4) / rate        # VAE decode/encode + ReferenceNet by FLOP ratio
-    clip_s = steps_ddim * t_unet + other
-    return {"value": frames / clip_s, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": sample + "; clip = %d x that + VAE/ReferenceNet by FLOP ratio (extrapolated); oracle build %.0f s"
-            % (steps_ddim, build_s), "unet_forward_s": t_unet}
+            return time.time() - t
+
+    last = None
+    for (S, Fr) in ((128, 4), (256, 8), (512, 16)):
+        if last is not None:
+            projected = last[2] * UNET_TFLOP[(S, Fr)] / UNET_TFLOP[last[:2]]
+            if (time.time() - t_start) + 1.3 * projected > budget_s:
+                break
+        t = unet_time(S, Fr)
+        last = (S, Fr, t)
+        t_unet = t * UNET_TFLOP[(512, 16)] / UNET_TFLOP[(S, Fr)]
+        rate = UNET_TFLOP[(512, 16)] / t_unet                       # achieved CPU TFLOP/s on the UNet
+        other = (frames * 2.515 + 3 * 1.117 + 2.4) / rate           # VAE decode/encode + ReferenceNet by FLOP ratio
+        clip_s = steps_ddim * t_unet + other
+        meas = "measured" if (S, Fr) == (512, 16) else "scaled by the FLOP ratio %.2f/%.3f to 512x512x16f" % (
+            UNET_TFLOP[(512, 16)], UNET_TFLOP[(S, Fr)])
+        print(json.dumps({
+            "value": frames / clip_s, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 oracle UNet3D forward (full width, B=1, fp32) at %dx%dx%df = %.1f s, %s; clip = %d x that + "
+                      "VAE/ReferenceNet by FLOP ratio (extrapolated); oracle build %.0f s"
+                      % (S, S, Fr, t, meas, steps_ddim, build_s),
+            "unet_forward_s": t_unet}), flush=True)
+
+
+def cpu_baseline(frames, steps_ddim, budget_s=150.0):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--frames", str(frames),
+           "--ddim-steps", str(steps_ddim), "--cpu-budget", str(budget_s)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    lines = []
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s + 60.0, env=env, cwd=ROOT)
+        lines = p.stdout.splitlines()
+        err = p.stderr[-300:] if p.returncode else ""
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        lines = out.splitlines()
+        err = "worker hit the %.0f s wall limit" % (budget_s + 60.0)
+    best = None
+    for ln in lines:
+        if ln.startswith("{"):
+            try:
+                best = json.loads(ln)
+            except ValueError:
+                pass
+    if best is None:
+        return {"value": None, "unit": "frames/s", "cores": usable_cores(), "kind": "port", "sample": "failed: " + err}
+    if err:
+        best["sample"] += "; " + err
+    return best
 
 
 # ------------------------------------------------------------------------------------------------
@@ -214,9 +266,14 @@ def main():
     ap.add_argument("--guidance", type=float, default=1.0, help="1.0 = BASELINE config #2 (no CFG); 3.5 = config #3")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help="internal: child process of cpu_baseline()")
+    ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds of host time the CPU baseline may use")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--shape-breakdown", action="store_true", help="write gpurun_out/shape_breakdown.json (per op x shape times)")
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(args.frames, args.ddim_steps, args.cpu_budget)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -328,8 +385,9 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(Fr, args.ddim_steps)
-            out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            out["cpu_baseline"] = cpu_baseline(Fr, args.ddim_steps, args.cpu_budget)
+            if out["cpu_baseline"]["value"]:
+                out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         except Exception as e:  # the baseline is a reported extra; never lose the GPU number to it
             out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}

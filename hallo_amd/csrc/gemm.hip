@@ -19,6 +19,7 @@
 // In conv mode the A operand is gathered on the fly: K index = (ky*3+kx)*Cin + c, zero padding,
 // optional stride 2, optional nearest-2x upsample folded into the gather (resnet.py:166-168).
 #include "common.h"
+#include "gemm_args.h"
 #include "../../include/hallo_amd.h"
 #include <string.h>
 
@@ -27,30 +28,6 @@ namespace hallo {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDS_LD = BK + 8;  // elements per LDS row (144 bytes)
 
-struct GemmArgs {
-  const void* A; const void* B; void* C;
-  int M, N, K;
-  long lda, ldb, ldc;
-  long sA, sB, sC;          // batch strides (elements)
-  const void* bias;         // [N] (or [M] if bias_per_row) or null; for GEGLU: [2N]
-  int bias_per_row;
-  const void* bias2;        // [M/bias2_rpg, N] or null
-  int bias2_rpg;
-  long bias2_ld;
-  const float* rowscale;    // [M] fp32 or null
-  const void* residual;     // [M,N] (ld = ldr) or null
-  long ldr, sR;
-  float alpha;
-  int act;
-  int out_f32;
-  int tiles_n, tiles_m;
-  int splits, nk_per_split;   // split-K: blockIdx.y = split, each split owns nk_per_split K tiles
-  float* slab;                // fp32 partial sums [splits][M][N] (splits > 1)
-  int vec_ok, res_vec_ok, bias_vec_ok, bias2_vec_ok;   // 8-byte (fp32: 16-byte) row accesses are aligned
-  // conv gather
-  int H, W, Cin, OH, OW, stride, pad_t, pad_l, upsample;
-  int conv_fast;   // Cin % 64 == 0 and no upsample: one tap per K tile, scalar tap offsets
-};
 
 template <typename T, bool CONV, bool GEGLU>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
@@ -697,20 +674,78 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
-static int g_gemm_variant = 3;   // 0: v1 (register-staged), 1 / 2: v2 with 1 / 2 LDS stages, 3: auto (1 or 2 by grid size)
+// gemm_variant: 0 v1 (register-staged 128x128), 1 / 2 v2 (LDS-DMA 128x128) with 1 / 2 LDS stages, 3 auto among v2 only,
+// 4 / 5 force the 256x320 / 128x320 kernel of gemm3.hip wherever it is applicable, 6 auto over everything (default)
+static int g_gemm_variant = 6;
 static int g_split_k = 1;        // 0: never split K, 1: auto
 static int g_conv_fast = 1;      // 0: always use the general (per-thread tap) conv gather
+static int g_v3_min_tiles = 192; // auto: smallest grid (workgroups, 1 per CU) worth the big-tile kernel
 
 
 template <typename T>
 static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
-  const int tiles = a.tiles_m * a.tiles_n;
+  const int nk = (a.K + BK - 1) / BK;
+  a.splits = 1; a.nk_per_split = 0; a.slab = nullptr;
   int v = a.vec_ok ? g_gemm_variant : 0;
+
+  // ---- big-tile kernel (gemm3.hip): 256x320 or 128x320 output tiles, one workgroup per CU ----
+  if (v >= 4) {
+    const bool ok3 = (a.K % 64 == 0) && (!conv || a.conv_fast) && a.N >= 160;
+    const int tn3 = geglu ? (a.N + 159) / 160 : (a.N + 319) / 320;
+    const float n_eff = (float)a.N / (float)(tn3 * (geglu ? 160 : 320));
+    const int t256 = ((a.M + 255) / 256) * tn3 * batch, t128 = ((a.M + 127) / 128) * tn3 * batch;
+    int tm = 0, sp = 1;
+    // Split-K factor that brings a grid of `tiles` workgroups to ~one per CU (long K only; fp32 slabs + reduce pass).
+    auto split_for = [&](int tiles) {
+      if (tiles >= g_v3_min_tiles || geglu || batch != 1 || !g_split_k || !ws || nk < 16) return 1;
+      int f = (256 + tiles - 1) / tiles;
+      if (f > nk / 8) f = nk / 8;
+      if (f > 8) f = 8;
+      while (f > 1 && (int64_t)f * a.M * a.N * 4 > ws_bytes) --f;
+      return f < 1 ? 1 : f;
+    };
+    if (ok3) {
+      if (v == 4) { tm = 2; sp = split_for(t256); }
+      else if (v == 5) { tm = 1; sp = split_for(t128); }
+      else if (n_eff > 0.8f) {
+        // Auto rule, from tools/kernel_bench.py on MI355X (profiles/r1_kernel_bench_gemm_variants.txt): the big tile pays
+        // when the K loop is long enough to amortise its prologue / 6-pass epilogue with one workgroup per CU:
+        //   conv3x3 (K = 9 Cin >= 576): always; 256-row tiles when the grid (after split-K) keeps >= 64 K steps per
+        //   workgroup, else 128-row tiles;  GEMM / GEGLU: K >= 1280 and a grid that fills the chip.
+        const int sp256 = split_for(t256), sp128 = split_for(t128);
+        if (conv && a.stride == 1) {
+          if (t256 >= 256 || (t256 * sp256 >= g_v3_min_tiles && nk / sp256 >= 64)) { tm = 2; sp = sp256; }
+          else if (t128 * sp128 >= 128) { tm = 1; sp = sp128; }
+        } else if (!conv && nk >= 20) {
+          if (t256 >= g_v3_min_tiles) { tm = 2; sp = 1; }
+          else if (!geglu && nk >= 40 && t128 * sp128 >= g_v3_min_tiles) { tm = 1; sp = sp128; }
+        }
+      }
+    }
+    if (tm) {
+      a.tiles_m = (a.M + 128 * tm - 1) / (128 * tm);
+      a.tiles_n = tn3;
+      if (sp > 1) {
+        a.nk_per_split = (nk + sp - 1) / sp;
+        a.splits = (nk + a.nk_per_split - 1) / a.nk_per_split;
+        a.slab = reinterpret_cast<float*>(ws);
+      }
+      launch_gemm3<T>(a, geglu ? 2 : (conv ? 1 : 0), tm, batch, st);
+      HALLO_CHECK_LAUNCH();
+      if (a.splits > 1) {
+        const long n = (long)a.M * (a.N / 8);
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+        HALLO_CHECK_LAUNCH();
+      }
+      return 0;
+    }
+    v = 3;
+  }
+
+  const int tiles = a.tiles_m * a.tiles_n;
   // auto: one LDS stage (4 workgroups per CU hide each other's load latency) when the grid fills the chip several
   // times over, two stages (in-workgroup prefetch) for small grids
   if (v == 3) v = (tiles * batch >= 640) ? 1 : 2;
-  a.splits = 1; a.nk_per_split = 0; a.slab = nullptr;
-  const int nk = (a.K + BK - 1) / BK;
   if (v != 0 && !geglu && batch == 1 && g_split_k && ws && tiles < 384 && nk >= 32) {
     // small grids with a long K loop (8x8 / 16x16 feature maps, K up to 23040): split K so that >= ~768 workgroups
     // are in flight; partial sums go to an fp32 slab and a second pass applies the epilogue in a fixed order
@@ -819,7 +854,8 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
 
 extern "C" int hallo_set_option(const char* name, int value) {
   if (!name) return -22;
-  if (!strcmp(name, "gemm_variant")) { if (value < 0 || value > 3) return -22; g_gemm_variant = value; return 0; }
+  if (!strcmp(name, "gemm_variant")) { if (value < 0 || value > 6) return -22; g_gemm_variant = value; return 0; }
+  if (!strcmp(name, "v3_min_tiles")) { if (value < 1) return -22; g_v3_min_tiles = value; return 0; }
   if (!strcmp(name, "conv_fast")) { if (value < 0 || value > 1) return -22; g_conv_fast = value; return 0; }
   if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }
   return -22;

@@ -1,0 +1,36 @@
+// Kernel argument block shared by the GEMM / implicit-GEMM conv kernels (gemm.hip, gemm3.hip).
+#pragma once
+#include "common.h"
+
+namespace hallo {
+
+struct GemmArgs {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  long sA, sB, sC;          // batch strides (elements)
+  const void* bias;         // [N] (or [M] if bias_per_row) or null; for GEGLU: [2N]
+  int bias_per_row;
+  const void* bias2;        // [M/bias2_rpg, N] or null
+  int bias2_rpg;
+  long bias2_ld;
+  const float* rowscale;    // [M] fp32 or null
+  const void* residual;     // [M,N] (ld = ldr) or null
+  long ldr, sR;
+  float alpha;
+  int act;
+  int out_f32;
+  int tiles_n, tiles_m;
+  int splits, nk_per_split;   // split-K: blockIdx.y = split, each split owns nk_per_split K tiles
+  float* slab;                // fp32 partial sums [splits][M][N] (splits > 1)
+  int vec_ok, res_vec_ok, bias_vec_ok, bias2_vec_ok;   // 8-byte (fp32: 16-byte) row accesses are aligned
+  // conv gather
+  int H, W, Cin, OH, OW, stride, pad_t, pad_l, upsample;
+  int conv_fast;   // Cin % 64 == 0 and no upsample: one tap per K tile, scalar tap offsets
+};
+
+// gemm3.hip: 256x320 / 128x320 tile kernel (8 waves, LDS-DMA, one barrier per K step).  MODE 0 gemm, 1 conv3x3
+// (fast gather only: Cin % 64 == 0, no upsample), 2 geglu.  TM = 32-row blocks per wave along M (2 or 1).
+template <typename T> void launch_gemm3(const GemmArgs& a, int mode, int tm, int batch, hipStream_t st);
+
+}  // namespace hallo

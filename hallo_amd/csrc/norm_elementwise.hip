@@ -223,6 +223,65 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   }
 }
 
+// LayerNorm for C = 40 * LPR (320 / 640 / 1280: every LayerNorm width of the UNets): LPR = 8 / 16 / 32 lanes share a
+// row, 5 x 16-byte vectors per lane, so all 64 lanes of a wave load (the one-wave-per-row kernel above runs 40 of 64
+// lanes at C = 320) and a wave keeps 5 independent loads per lane in flight over 64 / LPR rows.
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void layernorm_sub_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                            const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                            const float* __restrict__ pe, long rows, int C, float eps,
+                                                            int pe_rpp, int pe_len) {
+  using V8 = typename Vec<T>::v8;
+  constexpr int RPW = 64 / LPR;             // rows per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (LPR - 1);
+  const long row = ((long)blockIdx.x * 4 + wave) * RPW + lane / LPR;
+  const bool live = row < rows;
+  const T* xr = x + (live ? row : 0) * C;
+  float v[5][8];
+  float sum = 0.0f;
+  V8 t[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) t[i] = ld8<T>(xr + (sub + LPR * i) * 8);
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[i][e] = to_f32(t[i][e]); sum += v[i][e]; }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)C;
+  float sq = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = rsqrtf(sq / (float)C + eps);
+  if (!live) return;
+  const float* per = pe ? pe + (long)((row / pe_rpp) % pe_len) * C : nullptr;
+  T* yr = y + row * C;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int c0 = (sub + LPR * i) * 8;
+    V8 g8 = ld8<T>(gamma + c0), b8 = ld8<T>(beta + c0);
+    float pe8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (per) {
+      const f32x4 p0 = *reinterpret_cast<const f32x4*>(per + c0), p1 = *reinterpret_cast<const f32x4*>(per + c0 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pe8[e] = p0[e]; pe8[4 + e] = p1[e]; }
+    }
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = (v[i][e] - mean) * rstd * to_f32(g8[e]) + to_f32(b8[e]);
+      if (per) f = to_f32(from_f32<T>(f)) + pe8[e];   // PE is added to the already-rounded LayerNorm output (motion_module.py:459)
+      o[e] = from_f32<T>(f);
+    }
+    st8<T>(yr + c0, o);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Row softmax (fp32 in, T out): one workgroup per row.
 // ------------------------------------------------------------------------------------------
@@ -409,6 +468,15 @@ static int launch_layernorm(const void* x, void* y, const void* g, const void* b
   T* yy = reinterpret_cast<T*>(y);
   const T* gg = reinterpret_cast<const T*>(g);
   const T* bb = reinterpret_cast<const T*>(b);
+  if (vpr == 40 || vpr == 80 || vpr == 160) {
+    const int lpr = vpr / 5, rpb = 4 * (64 / lpr);
+    dim3 g2((unsigned)((rows + rpb - 1) / rpb));
+    if (lpr == 8) hipLaunchKernelGGL((layernorm_sub_kernel<T, 8>), g2, block, 0, st, xx, yy, gg, bb, pe, rows, C, eps, rpp, plen);
+    else if (lpr == 16) hipLaunchKernelGGL((layernorm_sub_kernel<T, 16>), g2, block, 0, st, xx, yy, gg, bb, pe, rows, C, eps, rpp, plen);
+    else hipLaunchKernelGGL((layernorm_sub_kernel<T, 32>), g2, block, 0, st, xx, yy, gg, bb, pe, rows, C, eps, rpp, plen);
+    HALLO_CHECK_LAUNCH();
+    return 0;
+  }
   if (vpr <= 64) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, st, xx, yy, gg, bb, pe, rows, C, eps, rpp, plen);
   else if (vpr <= 128) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, st, xx, yy, gg, bb, pe, rows, C, eps, rpp, plen);
   else if (vpr <= 192) hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, st, xx, yy, gg, bb, pe, rows, C, eps, rpp, plen);

@@ -33,8 +33,10 @@ extern "C" {
 
 int hallo_abi_version(void);
 
-/* Tuning / A-B switch (not part of the numerical contract): "gemm_variant" = 0 register-staged v1 kernel,
- * 1 / 2 direct-to-LDS kernel with 1 / 2 LDS stages, 3 auto (default); "split_k" = 0 / 1 (auto, default).  Returns -22 for unknown names / values. */
+/* Tuning / A-B switch (not part of the numerical contract): "gemm_variant" = 0 register-staged 128x128 kernel,
+ * 1 / 2 direct-to-LDS 128x128 kernel with 1 / 2 LDS stages, 3 auto among those, 4 / 5 force the 256x320 / 128x320
+ * big-tile kernel wherever applicable, 6 auto over all (default); "split_k" = 0 / 1 (auto, default);
+ * "v3_min_tiles" = smallest grid the auto rule gives to the big-tile kernel.  Returns -22 for unknown names / values. */
 int hallo_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------

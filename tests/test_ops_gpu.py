@@ -141,6 +141,89 @@ def test_gemm_batched(dtype, report):
 
 
 # --------------------------------------------------------------------------------------------
+# Big-tile kernel (gemm3.hip: 256x320 / 128x320 tiles, 8 waves).  The auto rule only picks it for grids that fill
+# the chip, so the tests force it (gemm_variant 4 / 5) on shapes that exercise every edge: M and N tails, N below
+# one tile, all epilogue operands, GEGLU's value/gate interleave (incl. the mixed 64..79 block), the conv gather
+# across image borders / image boundaries inside a tile / stride 2, and split-K.
+@pytest.fixture
+def big_tile(request):
+    from hallo_amd import ops
+    ops.set_option("gemm_variant", request.param)
+    yield request.param
+    ops.set_option("gemm_variant", 6)
+
+
+@pytest.mark.parametrize("big_tile", [4, 5], indirect=True)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(256, 320, 64), (512, 640, 320), (1000, 328, 768), (70, 160, 2560), (4096, 960, 320),
+                                   (300, 1928, 128)])
+def test_gemm_big_tile(big_tile, dtype, M, N, K, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(M * 5 + N * 11 + K)
+    a = _rand((M, K), dtype, g)
+    w = _rand((N, K), dtype, g, K ** -0.5)
+    bias = _rand((N,), dtype, g)
+    res = _rand((M, N), dtype, g)
+    rs = torch.rand((M,), generator=g).to(_dev())
+    out = ops.gemm(a, w, bias)
+    _check(f"gemm3[v{big_tile}][{M},{N},{K}]", out, ops_ref.linear(a, w, bias), dtype, report)
+    out = ops.gemm(a, w, bias, residual=res, rowscale=rs, alpha=0.75)
+    ref = 0.75 * rs[:, None] * ops_ref.linear(a, w, bias) + res.float()
+    _check(f"gemm3_epilogue[v{big_tile}][{M},{N},{K}]", out, ref, dtype, report)
+    b2 = _rand(((M + 63) // 64, N), dtype, g)
+    out = ops.gemm(a, w, bias, bias2=b2, bias2_rows_per_group=64, act=ops.ACT_SILU)
+    ref = torch.nn.functional.silu(ops_ref.linear(a, w, bias) + b2.float().repeat_interleave(64, 0)[:M])
+    _check(f"gemm3_bias2_silu[v{big_tile}][{M},{N},{K}]", out, ref, dtype, report)
+    out = ops.gemm(a, w, None, out_f32=True)
+    assert out.dtype == torch.float32
+    _check(f"gemm3_out_f32[v{big_tile}][{M},{N},{K}]", out, ops_ref.linear(a, w), dtype, report)
+
+
+@pytest.mark.parametrize("big_tile", [4, 5], indirect=True)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Cd", [(300, 320), (1024, 640), (130, 40)])
+def test_gemm_geglu_big_tile(big_tile, dtype, M, Cd, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(9 + Cd)
+    K = 320
+    a = _rand((M, K), dtype, g)
+    w = _rand((8 * Cd, K), dtype, g, K ** -0.5)
+    bias = _rand((8 * Cd,), dtype, g)
+    out = ops.gemm(a, w, bias, geglu=True)
+    _check(f"gemm3_geglu[v{big_tile}][{M},{Cd}]", out, ops_ref.geglu(a, w, bias), dtype, report)
+
+
+@pytest.mark.parametrize("big_tile", [4, 5], indirect=True)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    dict(n=3, H=12, W=20, Cin=320, Cout=320, stride=1),     # tiles straddle image boundaries (240 px per image)
+    dict(n=2, H=16, W=16, Cin=64, Cout=640, stride=2),
+    dict(n=5, H=8, W=8, Cin=128, Cout=328, stride=1),       # N tail
+    dict(n=1, H=16, W=16, Cin=1280, Cout=320, stride=1),    # K = 11520: split-K (grid of 1-2 tiles)
+])
+def test_conv3x3_big_tile(big_tile, dtype, cfg, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(cfg["Cin"] + 3 * cfg["Cout"])
+    n, H, W, Cin, Cout = cfg["n"], cfg["H"], cfg["W"], cfg["Cin"], cfg["Cout"]
+    x = _rand((n, H * W, Cin), dtype, g)
+    w = _rand((Cout, Cin, 3, 3), dtype, g, (9 * Cin) ** -0.5)
+    bias = _rand((Cout,), dtype, g)
+    w_nhwc = w.permute(0, 2, 3, 1).contiguous()
+    out = ops.conv3x3(x, w_nhwc, bias, n, H, W, stride=cfg["stride"])
+    ref, oh, ow = ops_ref.conv3x3_nhwc(x, w, bias, n, H, W, stride=cfg["stride"])
+    assert out.shape[1] == oh * ow
+    _check(f"conv3x3_big[v{big_tile}][{cfg}]", out, ref, dtype, report)
+    if cfg["stride"] == 1:
+        temb = _rand((n, Cout), dtype, g)
+        res = _rand((n, H * W, Cout), dtype, g)
+        out = ops.conv3x3(x, w_nhwc, bias, n, H, W, bias2=temb, bias2_rows_per_group=H * W, residual=res)
+        _check(f"conv3x3_big_temb_res[v{big_tile}][{cfg}]", out, ref + temb.float()[:, None, :] + res.float(), dtype, report)
+
+
+# --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [
     dict(n=2, H=16, W=16, Cin=64, Cout=96, stride=1, up=False),

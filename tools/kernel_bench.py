@@ -35,7 +35,7 @@ def timeit(fn, iters=10, warm=2):
 
 
 res = []
-VARIANTS = (0, 1, 2, 3)
+VARIANTS = tuple(int(v) for v in os.environ.get('KB_VARIANTS', '3,4,5,6').split(','))
 
 
 def rel(a, b):
@@ -45,7 +45,7 @@ def rel(a, b):
 def bench_gemm():
     shapes = [(65536, 320, 320), (65536, 960, 320), (65536, 320, 1280), (73728, 960, 320), (16384, 640, 640),
               (16384, 1920, 640), (16384, 640, 2560), (4096, 1280, 1280), (4096, 3840, 1280), (4096, 1280, 5120),
-              (1024, 1280, 1280), (8192, 8192, 8192)]
+              (1024, 1280, 1280), (8192, 8192, 8192), (8192, 8000, 8192)]
     for M, N, K in shapes:
         a, w, b = rnd(M, K), rnd(N, K, sc=K ** -0.5), rnd(N)
         r = rnd(M, N)
@@ -74,6 +74,7 @@ def bench_gemm():
             rec = dict(op="geglu", variant=v, M=M, N=N, K=K, ms=ms, tflops=4.0 * M * N * K / ms / 1e9, rel_err=err)
             res.append(rec)
             print(rec, flush=True)
+    ops.set_option("gemm_variant", 6)
 
 
 def bench_conv():
@@ -104,7 +105,7 @@ def bench_conv():
                        tflops=2.0 * M * Cout * 9 * Cin / ms / 1e9, rel_err=err)
             res.append(rec)
             print(rec, flush=True)
-    ops.set_option("gemm_variant", 3)
+    ops.set_option("gemm_variant", 6)
 
 
 def bench_attn():
