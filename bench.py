@@ -269,6 +269,7 @@ def main():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help="internal: child process of cpu_baseline()")
     ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds of host time the CPU baseline may use")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--gemm-variant", type=int, default=None, help="A/B: hallo_set_option('gemm_variant', v) (default: library auto)")
     ap.add_argument("--shape-breakdown", action="store_true", help="write gpurun_out/shape_breakdown.json (per op x shape times)")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -288,6 +289,9 @@ def main():
 
     from hallo_amd import lib
     lib.load()
+    if args.gemm_variant is not None:
+        from hallo_amd import ops as _ops
+        _ops.set_option("gemm_variant", args.gemm_variant)
     from hallo_amd.synthetic import build_pipeline, clip_inputs
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     pipe, audioproj = build_pipeline(dev, dtype)
@@ -359,7 +363,8 @@ def main():
                          tflops=round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0,
                          gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0) for k, v in top]
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "shape_breakdown.json"), "w") as f:
+            tag = "" if args.gemm_variant is None else "_v%d" % args.gemm_variant
+            with open(os.path.join(ROOT, "gpurun_out", "shape_breakdown%s.json" % tag), "w") as f:
                 json.dump(rows, f, indent=1)
         tot_ms = sum(d["ms"] for d in fam.values())
         tot_flop = sum(d["flop"] for d in fam.values())

@@ -21,6 +21,7 @@
 // from LDS with the same permutation (two 8-byte reads per fragment).
 #include "common.h"
 #include "../../include/hallo_amd.h"
+#include <type_traits>
 
 namespace hallo {
 
@@ -31,10 +32,13 @@ struct AttnArgs {
   int kv2_div, kv2_mod, kv2_first;
   float scale_log2e;
   int nqb;  // query blocks per (batch, head)
+  const float* o_rowscale;   // optional fp32 output row scale: o[b, q, head h] *= o_rowscale[(h / rs_hdiv) * rs_stride + b * Lq + q]
+  int rs_hdiv;
+  long rs_stride;
 };
 
 template <typename T, int HD>
-__global__ __launch_bounds__(256, HD <= 80 ? 2 : 1) void attn_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, HD <= 40 ? 3 : (HD <= 80 ? 2 : 1)) void attn_kernel(const AttnArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   constexpr int KVB = (HD > 80) ? 32 : 64;       // kv rows per tile
@@ -102,38 +106,91 @@ __global__ __launch_bounds__(256, HD <= 80 ? 2 : 1) void attn_kernel(const AttnA
   const int nt2 = use2 ? (p.Lkv2 + KVB - 1) / KVB : 0;
   const int nt = nt1 + nt2;
 
-  V8 rk[KU];
-  V8 rv[VU][2];
-  auto load_tile = [&](int it) {
-    const bool s2 = it >= nt1;
-    const T* Kp = s2 ? K2 : K1;
-    const T* Vp = s2 ? V2 : V1;
-    const long krs = s2 ? p.k2_rs : p.k1_rs, vrs = s2 ? p.v2_rs : p.v1_rs;
-    const int L = s2 ? p.Lkv2 : p.Lkv1;
-    const int kv0 = (s2 ? it - nt1 : it) * KVB;
+  // ---- K/V loaders: buffer loads with per-thread byte offsets computed once per segment and the tile advance in the
+  // scalar offset (no per-tile address arithmetic); rows past the segment end (ragged last tile only) use an
+  // out-of-range offset and read zeros ----
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  auto clamp32 = [](long bytes) { return (int)(bytes > 0xFFFFFFFFL ? 0xFFFFFFFFL : (bytes < 0 ? 0 : bytes)); };
+  auto mk_rsrc = [&](const T* base, long rs, int L) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, clamp32(((long)(L - 1) * rs + HD) * 2), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsK1 = mk_rsrc(K1, p.k1_rs, p.Lkv1), rsV1 = mk_rsrc(V1, p.v1_rs, p.Lkv1);
+  const __amdgpu_buffer_rsrc_t rsK2 = mk_rsrc(K2, use2 ? p.k2_rs : p.k1_rs, use2 ? p.Lkv2 : p.Lkv1);
+  const __amdgpu_buffer_rsrc_t rsV2 = mk_rsrc(V2, use2 ? p.v2_rs : p.v1_rs, use2 ? p.Lkv2 : p.Lkv1);
+  // K and V run on separate tile counters (the pipelined loop below stages K two tiles ahead and V one tile ahead),
+  // so each has its own segment state.
+  unsigned offK[KU], offV[VU][2];
+  auto set_segment_k = [&](long krs) {
 #pragma unroll
     for (int i = 0; i < KU; ++i) {
       const int u = tid + 256 * i;
-      if (u < KVB * NCH) {
-        const int row = u / NCH, ch = u - row * NCH;
-        const int kv = min(kv0 + row, L - 1);
-        rk[i] = ld8<T>(Kp + (long)kv * krs + ch * 8);
-      }
+      const int row = u / NCH, ch = u - row * NCH;
+      offK[i] = (u < KVB * NCH) ? (unsigned)((row * krs + ch * 8) * 2) : OOB;
     }
+  };
+  auto set_segment_v = [&](long vrs) {
 #pragma unroll
     for (int i = 0; i < VU; ++i) {
       const int u = tid + 256 * i;
-      if (u < (KVB / 2) * NCH) {
-        const int pr = u % (KVB / 2), ch = u / (KVB / 2);
-        const int kva = min(kv0 + 2 * pr, L - 1), kvb = min(kv0 + 2 * pr + 1, L - 1);
-        rv[i][0] = ld8<T>(Vp + (long)kva * vrs + ch * 8);
-        rv[i][1] = ld8<T>(Vp + (long)kvb * vrs + ch * 8);
+      const int pr = u % (KVB / 2), ch = u / (KVB / 2);
+      const bool ok = u < (KVB / 2) * NCH;
+      offV[i][0] = ok ? (unsigned)((2 * pr * vrs + ch * 8) * 2) : OOB;
+      offV[i][1] = ok ? (unsigned)(((2 * pr + 1) * vrs + ch * 8) * 2) : OOB;
+    }
+  };
+  set_segment_k(p.k1_rs);
+  set_segment_v(p.v1_rs);
+
+  V8 rk[KU];
+  V8 rv[VU][2];
+  auto ldb = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, int soff) {
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0);
+    return __builtin_bit_cast(V8, r);
+  };
+  auto load_k = [&](int it) {
+    const bool s2 = it >= nt1;
+    if (it == nt1) set_segment_k(p.k2_rs);     // wave-uniform, once per kernel
+    const long krs = s2 ? p.k2_rs : p.k1_rs;
+    const int L = s2 ? p.Lkv2 : p.Lkv1;
+    const int kv0 = (s2 ? it - nt1 : it) * KVB;
+    const int soK = (int)(kv0 * krs * 2);
+    if (kv0 + KVB <= L) {
+#pragma unroll
+      for (int i = 0; i < KU; ++i) rk[i] = s2 ? ldb(rsK2, offK[i], soK) : ldb(rsK1, offK[i], soK);
+    } else {
+#pragma unroll
+      for (int i = 0; i < KU; ++i) {
+        const unsigned o = (kv0 + (tid + 256 * i) / NCH < L) ? offK[i] : OOB;
+        rk[i] = s2 ? ldb(rsK2, o, soK) : ldb(rsK1, o, soK);
       }
     }
   };
-  auto store_tile = [&](int stage) {
+  auto load_v = [&](int it) {
+    const bool s2 = it >= nt1;
+    if (it == nt1) set_segment_v(p.v2_rs);
+    const long vrs = s2 ? p.v2_rs : p.v1_rs;
+    const int L = s2 ? p.Lkv2 : p.Lkv1;
+    const int kv0 = (s2 ? it - nt1 : it) * KVB;
+    const int soV = (int)(kv0 * vrs * 2);
+    if (kv0 + KVB <= L) {
+#pragma unroll
+      for (int i = 0; i < VU; ++i) {
+        rv[i][0] = s2 ? ldb(rsV2, offV[i][0], soV) : ldb(rsV1, offV[i][0], soV);
+        rv[i][1] = s2 ? ldb(rsV2, offV[i][1], soV) : ldb(rsV1, offV[i][1], soV);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < VU; ++i) {
+        const int r0 = 2 * ((tid + 256 * i) % (KVB / 2));
+        const unsigned o0 = (kv0 + r0 < L) ? offV[i][0] : OOB, o1 = (kv0 + r0 + 1 < L) ? offV[i][1] : OOB;
+        rv[i][0] = s2 ? ldb(rsV2, o0, soV) : ldb(rsV1, o0, soV);
+        rv[i][1] = s2 ? ldb(rsV2, o1, soV) : ldb(rsV1, o1, soV);
+      }
+    }
+  };
+  auto store_k = [&](int stage) {
     T* sK = sK0 + stage * SK_ELEMS;
-    T* sVT = sVT0 + stage * SVT_ELEMS;
 #pragma unroll
     for (int i = 0; i < KU; ++i) {
       const int u = tid + 256 * i;
@@ -142,6 +199,9 @@ __global__ __launch_bounds__(256, HD <= 80 ? 2 : 1) void attn_kernel(const AttnA
         st8<T>(&sK[row * K_LD + ch * 8], rk[i]);
       }
     }
+  };
+  auto store_v = [&](int stage) {
+    T* sVT = sVT0 + stage * SVT_ELEMS;
 #pragma unroll
     for (int i = 0; i < VU; ++i) {
       const int u = tid + 256 * i;
@@ -167,54 +227,77 @@ __global__ __launch_bounds__(256, HD <= 80 ? 2 : 1) void attn_kernel(const AttnA
     for (int r = 0; r < 16; ++r) oacc[db][r] = 0.0f;
   float m_run = -1e30f, l_run = 0.0f;
   constexpr float RESCALE_THR = 6.0f;   // log2 units: P <= 64
+  const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
-  if (nt > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
-
-  for (int it = 0; it < nt; ++it) {
-    if (it + 1 < nt) load_tile(it + 1);
-    const T* sK = sK0 + (it & 1) * SK_ELEMS;
-    const T* sVT = sVT0 + (it & 1) * SVT_ELEMS;
-
-    // ---- S^T = K . Q^T ----
-    f32x16 s[NT];
-    const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  // S^T = K . Q^T of one K stage
+  auto qk = [&](const T* sK, f32x16* sc) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         V8 kf = ld8<T>(&sK[(t * 32 + l31) * K_LD + ks * 16 + hi * 8]);
-        s[t] = Vec<T>::mfma32(kf, qf[ks], ks == 0 ? zero16 : s[t]);   // C = inline 0 on the first k-step
+        sc[t] = Vec<T>::mfma32(kf, qf[ks], ks == 0 ? zero16 : sc[t]);   // C = inline 0 on the first k-step
       }
     }
+  };
 
-    // ---- online softmax on the raw scores (lane-local row; partner lane^32 holds the other kv half) ----
-    // p = exp2(s * c - m) with c = scale * log2(e) folded into one FMA per element; v_exp_f32 directly
-    // (scores are bounded, no denormal handling needed).  Only the ragged last tile of a segment is masked.
+  // ---- software pipeline over the K/V tiles ----
+  // Iteration `it` runs, in ONE basic block, the QK^T MFMAs of tile it+1, the exp / convert VALU work of tile it and
+  // the PV MFMAs of tile it: the matrix pipe has independent work while the softmax of the current tile is on the
+  // VALU (a wave that does QK -> softmax -> PV in sequence leaves each pipe idle while it uses the other; measured
+  // on this kernel: MFMA busy 43 %, VALU busy 65 %, waves parked 43 % of their cycles).
+  // LDS: K is staged two tiles ahead (K(it+1) must be complete when iteration it starts), V one tile ahead; both
+  // double-buffered, ONE barrier per tile:
+  //   K(it+2) -> K stage it&1       (last read by QK(it) in iteration it-1)
+  //   V(it+1) -> V stage (it+1)&1   (last read by PV(it-1) in iteration it-1)
+  f32x16 s_cur[NT], s_nxt[NT];
+  if (nt > 0) {
+    load_k(0);
+    load_v(0);
+    store_k(0);
+    store_v(0);
+    if (nt > 1) {
+      load_k(1);
+      store_k(1);
+    }
+  }
+  __syncthreads();
+  if (nt > 0) qk(sK0, s_cur);
+
+  auto tile_step = [&](auto more_c, int it) {
+    constexpr bool MORE = decltype(more_c)::value;      // a tile it+1 exists
+    if (MORE) {
+      load_v(it + 1);
+      if (it + 2 < nt) load_k(it + 2);
+    }
+    const T* sVT = sVT0 + (it & 1) * SVT_ELEMS;
+
+    // ---- online softmax statistics on the raw scores of tile it (lane-local row; partner lane^32 holds the other
+    // kv half).  p = exp2(s * c - m) with c = scale * log2(e) folded into one FMA per element; only the ragged last
+    // tile of a segment is masked.
     const bool s2 = it >= nt1;
     const int L = s2 ? p.Lkv2 : p.Lkv1;
     const int kv0 = (s2 ? it - nt1 : it) * KVB;
-    if (kv0 + KVB > L) {
+    if (__builtin_expect(kv0 + KVB > L, 0)) {
+      asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch: if-converted it costs ~100 VALU on EVERY tile
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kv = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          s[t][r] = (kv < L) ? s[t][r] : -3.0e38f;
+          s_cur[t][r] = (kv < L) ? s_cur[t][r] : -3.0e38f;
         }
     }
     float mx = -3.0e38f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(s[t][r], s[t][r + 1]), mx);
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(s_cur[t][r], s_cur[t][r + 1]), mx);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2e;
     // deferred rescale (keep the old reference max while the row max grew by < 2^RESCALE_THR): the O / l
     // rescale pass is skipped for most tiles; P stays <= 2^RESCALE_THR, exact in the fp32 accumulators.
-    if (!__all(mx - m_run <= RESCALE_THR)) {
+    if (__builtin_expect(!__all(mx - m_run <= RESCALE_THR), 0)) {
+      asm volatile("" ::: "memory");   // a real branch: the rescale pass runs on a handful of tiles per row block
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
@@ -224,20 +307,21 @@ __global__ __launch_bounds__(256, HD <= 80 ? 2 : 1) void attn_kernel(const AttnA
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
     }
+
+    // ---- one block: QK^T of tile it+1 | exp + convert of tile it | O^T += V^T . P^T of tile it ----
+    if (MORE) qk(sK0 + ((it + 1) & 1) * SK_ELEMS, s_nxt);
     float psum = 0.0f;
     V8 pf[NT][2];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], p.scale_log2e, -m_run));
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[t][r], p.scale_log2e, -m_run));
         if (!ONES_ROW) psum += pv;
         pf[t][r >> 3][r & 7] = from_f32<T>(pv);
       }
     }
     if (!ONES_ROW) l_run += psum;
-
-    // ---- O^T += V^T . P^T ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -256,15 +340,23 @@ __global__ __launch_bounds__(256, HD <= 80 ? 2 : 1) void attn_kernel(const AttnA
       }
     }
 
-    if (it + 1 < nt) store_tile((it + 1) & 1);   // other stage: last read in iteration it-1, behind that iteration's barrier
+    if (MORE) {
+      store_v((it + 1) & 1);
+      if (it + 2 < nt) store_k(it & 1);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) s_cur[t] = s_nxt[t];
+    }
     __syncthreads();
-  }
+  };
+  for (int it = 0; it + 1 < nt; ++it) tile_step(std::true_type{}, it);
+  if (nt > 0) tile_step(std::false_type{}, nt - 1);
 
   // ---- normalise and store: lane owns row q0+l31, d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
   float l_tot;
   if (ONES_ROW) l_tot = __shfl(oacc[L_DB][L_R], l31, 64);       // row HD of O^T lives in the hi = 0 lane of column q
   else l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  if (p.o_rowscale && q0 + l31 < p.Lq) inv *= p.o_rowscale[(long)(h / p.rs_hdiv) * p.rs_stride + (long)b * p.Lq + q0 + l31];
   if (q0 + l31 < p.Lq) {
     T* orow = Og + (long)(q0 + l31) * p.o_rs;
 #pragma unroll
@@ -392,6 +484,9 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
   a.kv2_mod = d->kv2_batch_mod;
   a.scale_log2e = d->scale * 1.4426950408889634f;
   a.nqb = (d->Lq + 127) / 128;
+  a.o_rowscale = d->o_rowscale;
+  a.rs_hdiv = d->o_rowscale_head_div > 0 ? d->o_rowscale_head_div : d->heads;
+  a.rs_stride = d->o_rowscale_stride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == DT_F16) return launch_attn<_Float16>(a, d->head_dim, st);
   if (d->dtype == DT_BF16) return launch_attn<__bf16>(a, d->head_dim, st);

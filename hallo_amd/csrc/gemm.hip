@@ -712,13 +712,15 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
         // when the K loop is long enough to amortise its prologue / 6-pass epilogue with one workgroup per CU:
         //   conv3x3 (K = 9 Cin >= 576): always; 256-row tiles when the grid (after split-K) keeps >= 64 K steps per
         //   workgroup, else 128-row tiles;  GEMM / GEGLU: K >= 1280 and a grid that fills the chip.
+        // One workgroup per CU: a grid of g workgroups runs in ceil(g / 256) rounds, so e.g. 288 tiles cost two full
+        // rounds (56 % efficiency).  Require >= 85 % of the last round to be filled.
+        auto fills = [&](int g) { const int rounds = (g + 255) / 256; return g >= g_v3_min_tiles && g * 100 >= rounds * 256 * 85; };
         const int sp256 = split_for(t256), sp128 = split_for(t128);
         if (conv && a.stride == 1) {
-          if (t256 >= 256 || (t256 * sp256 >= g_v3_min_tiles && nk / sp256 >= 64)) { tm = 2; sp = sp256; }
-          else if (t128 * sp128 >= 128) { tm = 1; sp = sp128; }
+          if (fills(t256 * sp256) && (sp256 == 1 || nk / sp256 >= 40)) { tm = 2; sp = sp256; }
+          else if (t128 <= 64 && fills(t128 * sp128)) { tm = 1; sp = sp128; }     // 8x8 feature maps: 128-row tiles, deep split
         } else if (!conv && nk >= 20) {
-          if (t256 >= g_v3_min_tiles) { tm = 2; sp = 1; }
-          else if (!geglu && nk >= 40 && t128 * sp128 >= g_v3_min_tiles) { tm = 1; sp = sp128; }
+          if (fills(t256)) { tm = 2; sp = 1; }
         }
       }
     }

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const T* __restrict__ mo,
 
 using namespace hallo;
 
-extern "C" int hallo_abi_version(void) { return 1; }
+extern "C" int hallo_abi_version(void) { return 2; }
 
 extern "C" int hallo_groupnorm_chunks(int HW) {
   int c = (HW + 63) / 64;   // 64 rows per partial-statistics block: >= 1024 blocks at 16 x 64x64 frames

@@ -75,6 +75,7 @@ class AttnDesc(C.Structure):
         ("kv2_batch_div", C.c_int), ("kv2_batch_mod", C.c_int), ("kv2_first_batch", C.c_int),
         ("scale", C.c_float),
         ("dtype", C.c_int),
+        ("o_rowscale", C.c_void_p), ("o_rowscale_head_div", C.c_int), ("o_rowscale_stride", C.c_int64),
     ]
 
 

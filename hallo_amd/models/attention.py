@@ -157,8 +157,21 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
 
     def _prepare(self):
         xs = (self.attn2_0, self.attn2_1, self.attn2_2)
+        cv = (self.zero_conv_full, self.zero_conv_face, self.zero_conv_lip)
+        D = self.zero_conv_full.weight.shape[0]
+        dt = self.zero_conv_full.weight.dtype
         self.w_q3 = torch.cat([a.to_q.weight for a in xs], dim=0).contiguous()         # [3D, D]
-        self.w_kv3 = torch.cat([torch.cat([a.to_k.weight, a.to_v.weight], 0) for a in xs], 0).contiguous()  # [6D, Ca]
+        # K rows of the three branches first, then the V rows: q3 / k / v of the three branches form ONE attention
+        # problem over 3 x heads heads
+        self.w_kv3 = torch.cat([a.to_k.weight for a in xs] + [a.to_v.weight for a in xs], 0).contiguous()  # [6D, Ca]
+        # to_out followed by the zero conv is one linear map per branch (the mask between them is a per-row scalar):
+        #   zero_conv_i(mask * (a_i Wo_i^T + bo_i)) = (mask * a_i) (Wz_i Wo_i)^T + mask * (Wz_i bo_i) + bz_i
+        # so the three branches + their sum are ONE GEMM over K = 3D (+8: three mask columns carrying Wz_i bo_i).
+        wz = [c.weight.view(D, D).float() for c in cv]
+        wc = [wz[i] @ xs[i].to_out[0].weight.float() for i in range(3)]
+        cc = [(wz[i] @ xs[i].to_out[0].bias.float())[:, None] for i in range(3)]
+        self.w_fused = torch.cat(wc + cc + [torch.zeros((D, 5), device=wc[0].device)], dim=1).to(dt).contiguous()   # [D, 3D+8]
+        self.bz3 = torch.stack([c.bias.float() for c in cv])                                                   # [3, D] fp32
 
     def run(self, x, audio, masks, motion_scale, cache=NO_CACHE):
         """x [n, L, D]; audio [n, 32, Ca]; masks = (full, face, lip), each fp32 [n, L] for this block's depth."""
@@ -172,19 +185,27 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
             T = audio.shape[1]
             return ops.gemm(audio.reshape(n * T, -1), self.w_kv3).view(n, T, 6 * D)
         kv3 = cache.get(self, "audio_kv", audio_kv)
+        ms = [1.0, 1.0, 1.0] if motion_scale is None else [float(m) for m in motion_scale]
+
+        # Step-invariant per depth (shared by every audio block of this depth through the clip cache):
+        # the fp32 row scales motion_scale[i] * mask_i and the staging buffer of the fused GEMM's A operand, whose
+        # last 8 columns hold those scales (columns 3D..3D+2) and zeros.
+        def scales():
+            return torch.stack([masks[i].reshape(-1).float() * ms[i] for i in range(3)]).contiguous()     # [3, n*L]
+        msmask = cache.get(AudioTemporalBasicTransformerBlock, ("msmask", self.depth, n, L), scales)
+
+        def abuf():
+            buf = torch.zeros((n * L, 3 * D + 8), device=x.device, dtype=x.dtype)
+            buf[:, 3 * D:3 * D + 3] = msmask.t().to(x.dtype)
+            return buf
+        A = cache.get(AudioTemporalBasicTransformerBlock, ("abuf", self.depth, n, L, D), abuf)
+        bias_c = cache.get(self, "bias_c", lambda: (torch.tensor(ms, device=x.device)[:, None] * self.bz3).sum(0).to(x.dtype))
 
         nh = self.norm2.run(x)
         q3 = ops.gemm(nh.view(n * L, D), self.w_q3).view(n, L, 3 * D)
-        attns = (self.attn2_0, self.attn2_1, self.attn2_2)
-        convs = (self.zero_conv_full, self.zero_conv_face, self.zero_conv_lip)
-        acc = x.view(n * L, D)
-        for i in range(3):
-            a = ops.attention(q3[:, :, i * D:(i + 1) * D], kv3[:, :, 2 * i * D:(2 * i + 1) * D],
-                              kv3[:, :, (2 * i + 1) * D:(2 * i + 2) * D], attns[i].heads)
-            # (to_out(a) + bias) * mask  -- attention.py:846-884
-            h = attns[i].to_out[0].run(a.view(n * L, D), rowscale=masks[i].reshape(-1))
-            # motion_scale[i] * zero_conv(h) + running sum  -- attention.py:865-903
-            ms = 1.0 if motion_scale is None else float(motion_scale[i])
-            acc = convs[i].run(h, alpha=ms, residual=acc)
-        x = acc.view(n, L, D)
+        # three branches x heads as one attention launch; output rows pre-scaled by motion_scale[i] * mask_i
+        # (attention.py:853-903) and written straight into the fused GEMM's A operand
+        ops.attention(q3, kv3[:, :, :3 * D], kv3[:, :, 3 * D:], 3 * self.attn2_0.heads,
+                      out=A.view(n, L, 3 * D + 8)[:, :, :3 * D], rowscale=msmask, rowscale_head_div=self.attn2_0.heads)
+        x = ops.gemm(A, self.w_fused, bias_c, residual=x.view(n * L, D)).view(n, L, D)
         return self.ff.run(self.norm3.run(x), residual=x)

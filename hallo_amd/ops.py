@@ -152,7 +152,7 @@ def conv3x3(x, w, bias, n_img, H, W, *, stride=1, pad_t=1, pad_l=1, out_hw=None,
 
 
 def attention(q, k1, v1, heads, *, k2=None, v2=None, kv2_batch_div=1, kv2_batch_mod=0, kv2_first_batch=0, out=None,
-              scale=None):
+              scale=None, rowscale=None, rowscale_head_div=0):
     """softmax(q k^T * scale) v over up to two key/value segments.
 
     q [B, Lq, C], k1/v1 [B, Lkv1, C], k2/v2 [B2, Lkv2, C] are views with contiguous last dim
@@ -183,6 +183,14 @@ def attention(q, k1, v1, heads, *, k2=None, v2=None, kv2_batch_div=1, kv2_batch_
     d.kv2_batch_div, d.kv2_batch_mod, d.kv2_first_batch = kv2_batch_div, kv2_batch_mod, kv2_first_batch
     d.scale = float(scale if scale is not None else hd ** -0.5)
     d.dtype = dtype_code(q.dtype)
+    if rowscale is not None:
+        # fp32 [G, B*Lq]: head h is scaled by row h // rowscale_head_div of it (G = heads // rowscale_head_div groups)
+        assert rowscale.dtype == torch.float32 and rowscale.is_contiguous()
+        groups = heads // rowscale_head_div if rowscale_head_div > 0 else 1
+        assert rowscale.numel() == groups * B * Lq, (rowscale.shape, groups, B, Lq)
+        d.o_rowscale, d.o_rowscale_head_div, d.o_rowscale_stride = rowscale.data_ptr(), rowscale_head_div, B * Lq
+    else:
+        d.o_rowscale, d.o_rowscale_head_div, d.o_rowscale_stride = None, 0, 0
     _l.check(_l.load().hallo_attention(C.byref(d), _stream()), "hallo_attention")
     return out
 

@@ -132,6 +132,13 @@ typedef struct hallo_attn_desc {
   int kv2_first_batch;  /* batches below this index skip segment 2 (CFG uncond half) */
   float scale;          /* head_dim^-0.5 */
   int dtype;
+  /* Optional fp32 output row scale (ABI v2): o[b, q, head h] *= o_rowscale[(h / o_rowscale_head_div) * o_rowscale_stride
+   * + b * Lq + q].  Carries `motion_scale[i] * mask_i[level]` of the hierarchical audio cross-attention
+   * (hallo/models/attention.py:853-903) so that the three branches run as ONE launch over 3 x heads heads
+   * (head_div = heads per branch, stride = batch * Lq); null = no scaling. */
+  const float* o_rowscale;
+  int o_rowscale_head_div;      /* <= 0: all heads share one scale vector */
+  int64_t o_rowscale_stride;
 } hallo_attn_desc;
 int hallo_attention(const hallo_attn_desc* d, void* stream);
 

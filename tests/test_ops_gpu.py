@@ -317,6 +317,30 @@ def test_attention_reference_segment_cfg(dtype, hd, L, report):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd,L", [(40, 300), (80, 64), (160, 16)])
+def test_attention_audio_branches_one_launch(dtype, hd, L, report):
+    """The three hierarchical audio cross-attentions (32 audio tokens, attention.py:846-884) as ONE launch over
+    3 x 8 heads with the per-branch output row scale motion_scale[i] * mask_i, written into a column slice of a
+    wider buffer (the fused to_out / zero-conv GEMM's A operand)."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(hd + 7 * L)
+    n, H, T = 3, 8, 32
+    D = H * hd
+    q3 = _rand((n, L, 3 * D), dtype, g)
+    kv3 = _rand((n, T, 6 * D), dtype, g)
+    rs = (torch.rand((3, n * L), generator=g) * 1.5).to(_dev())
+    buf = torch.full((n * L, 3 * D + 8), 7.0, device=_dev(), dtype=dtype)
+    out = ops.attention(q3, kv3[:, :, :3 * D], kv3[:, :, 3 * D:], 3 * H, out=buf.view(n, L, 3 * D + 8)[:, :, :3 * D],
+                        rowscale=rs, rowscale_head_div=H)
+    for i in range(3):
+        ref = ops_ref.sdpa(q3[:, :, i * D:(i + 1) * D], kv3[:, :, i * D:(i + 1) * D],
+                           kv3[:, :, (3 + i) * D:(4 + i) * D], H) * rs[i].view(n, L, 1)
+        _check(f"attn_audio3[{hd},{L}] branch {i}", out[:, :, i * D:(i + 1) * D], ref, dtype, report)
+    assert (buf[:, 3 * D:].float() == 7.0).all(), "columns outside the output slice must be untouched"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_forced_rescale(dtype, report):
     """One key far above the rest late in the sequence forces the online-softmax rescale path."""
     from hallo_amd import ops
