@@ -37,7 +37,13 @@ struct AttnArgs {
   long rs_stride;
 };
 
-template <typename T, int HD>
+// PRE = q already carries scale * log2(e) (hallo_gemm lead_alpha).  For head dim 40 the QK^T contraction is padded
+// to 48: pad column 40 of every K row in LDS is 1.0 and pad element 40 of the lane's Q row holds -m_run (kept exactly
+// representable in T), so the scores leave the MFMA as s * c - m_run and the per-score VALU work is exp2 + convert
+// only -- no v_fma / v_sub per score.  On the head-dim-40 shapes the kernel is VALU-bound (PMC: VALU busy 68 %,
+// MFMA 40 %; a plain VALU op costs 4 cycles and v_exp_f32 8 cycles per wave64), so this removes ~17 % of the VALU
+// cycles per tile.  Other head dims (no pad column) subtract m_run on the VALU as before.
+template <typename T, int HD, bool PRE>
 __global__ __launch_bounds__(256, HD <= 40 ? 3 : (HD <= 80 ? 2 : 1)) void attn_kernel(const AttnArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
@@ -54,6 +60,7 @@ __global__ __launch_bounds__(256, HD <= 40 ? 3 : (HD <= 80 ? 2 : 1)) void attn_k
   // Row sums for free: when the padded O^T block has a spare row (hd 40 -> 64 rows, 80 -> 96), V^T row HD is set to
   // all ones, so the PV MFMA accumulates sum_kv P into O^T[HD][q] -- rescaled together with O, no VALU adds.
   constexpr bool ONES_ROW = (NDB * 32 > HD);
+  constexpr bool PADM = PRE && (HDP > HD);       // -m_run rides in pad column HD of the QK^T contraction
   constexpr int L_DB = HD / 32, L_R = ((HD % 32) / 8) * 4 + (HD % 4);   // accumulator slot of row HD (lanes hi = 0); HD % 8 == 0
 
   // two LDS stages for K and V^T: tile it+1 is written into the other stage while tile it is consumed, so the
@@ -84,7 +91,9 @@ __global__ __launch_bounds__(256, HD <= 40 ? 3 : (HD <= 80 ? 2 : 1)) void attn_k
 
   // zero the K pad columns (HD..HDP-1) once; the loaders never touch them
   if (HDP > HD) {
-    for (int r = tid; r < 2 * KVB; r += 256) st8<T>(&sK0[r * K_LD + NCH * 8], zero8<T>());   // both stages (contiguous)
+    V8 padv = zero8<T>();
+    if (PADM) padv[0] = from_f32<T>(1.0f);
+    for (int r = tid; r < 2 * KVB; r += 256) st8<T>(&sK0[r * K_LD + NCH * 8], padv);   // both stages (contiguous)
   }
 
   if (ONES_ROW) {
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256, HD <= 40 ? 3 : (HD <= 80 ? 2 : 1)) void attn_k
   for (int db = 0; db < NDB; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[db][r] = 0.0f;
-  float m_run = -1e30f, l_run = 0.0f;
+  float m_run = PADM ? 0.0f : -1e30f, l_run = 0.0f;
   constexpr float RESCALE_THR = 6.0f;   // log2 units: P <= 64
   const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(256, HD <= 40 ? 3 : (HD <= 80 ? 2 : 1)) void attn_k
   // double-buffered, ONE barrier per tile:
   //   K(it+2) -> K stage it&1       (last read by QK(it) in iteration it-1)
   //   V(it+1) -> V stage (it+1)&1   (last read by PV(it-1) in iteration it-1)
-  f32x16 s_cur[NT], s_nxt[NT];
+  f32x16 s_a[NT], s_b[NT];     // score tiles of the current / next K tile; the roles swap every iteration
   if (nt > 0) {
     load_k(0);
     load_v(0);
@@ -262,9 +271,9 @@ __global__ __launch_bounds__(256, HD <= 40 ? 3 : (HD <= 80 ? 2 : 1)) void attn_k
     }
   }
   __syncthreads();
-  if (nt > 0) qk(sK0, s_cur);
+  if (nt > 0) qk(sK0, s_a);
 
-  auto tile_step = [&](auto more_c, int it) {
+  auto tile_step = [&](auto more_c, int it, f32x16* s_cur, f32x16* s_nxt) {
     constexpr bool MORE = decltype(more_c)::value;      // a tile it+1 exists
     if (MORE) {
       load_v(it + 1);
@@ -293,19 +302,42 @@ __global__ __launch_bounds__(256, HD <= 40 ? 3 : (HD <= 80 ? 2 : 1)) void attn_k
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(s_cur[t][r], s_cur[t][r + 1]), mx);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2e;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     // deferred rescale (keep the old reference max while the row max grew by < 2^RESCALE_THR): the O / l
     // rescale pass is skipped for most tiles; P stays <= 2^RESCALE_THR, exact in the fp32 accumulators.
-    if (__builtin_expect(!__all(mx - m_run <= RESCALE_THR), 0)) {
-      asm volatile("" ::: "memory");   // a real branch: the rescale pass runs on a handful of tiles per row block
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      if (!ONES_ROW) l_run *= alpha;
+    if (PADM) {
+      // s_cur holds s*c - m_run (m_run = 0 before the first tile, which always takes this branch)
+      if (__builtin_expect(it == 0 || !__all(mx <= RESCALE_THR), 0)) {
+        asm volatile("" ::: "memory");   // a real branch: the rescale pass runs on a handful of tiles per row block
+        const float want = m_run + (it == 0 ? mx : fmaxf(mx, 0.0f));
+        const float m_new = to_f32(from_f32<T>(want));          // any reference value works; it must be exact in T
+        const float delta = m_new - m_run;
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        m_run = m_new;
+        if (hi) qf[NKS - 1][HD - (NKS - 1) * 16 - 8] = from_f32<T>(-m_new);   // Q'[row][HD]: lanes hi = 1 hold d = HD .. HD+7
+        if (!ONES_ROW) l_run *= alpha;
 #pragma unroll
-      for (int db = 0; db < NDB; ++db)
+        for (int db = 0; db < NDB; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s_cur[t][r] -= delta;
+      }
+    } else {
+      if (!PRE) mx *= p.scale_log2e;
+      if (__builtin_expect(!__all(mx - m_run <= RESCALE_THR), 0)) {
+        asm volatile("" ::: "memory");   // a real branch: the rescale pass runs on a handful of tiles per row block
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        if (!ONES_ROW) l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      }
     }
 
     // ---- one block: QK^T of tile it+1 | exp + convert of tile it | O^T += V^T . P^T of tile it ----
@@ -316,7 +348,9 @@ __global__ __launch_bounds__(256, HD <= 40 ? 3 : (HD <= 80 ? 2 : 1)) void attn_k
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[t][r], p.scale_log2e, -m_run));
+        const float pv = PADM ? __builtin_amdgcn_exp2f(s_cur[t][r])
+                       : PRE ? __builtin_amdgcn_exp2f(s_cur[t][r] - m_run)
+                             : __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[t][r], p.scale_log2e, -m_run));
         if (!ONES_ROW) psum += pv;
         pf[t][r >> 3][r & 7] = from_f32<T>(pv);
       }
@@ -343,13 +377,22 @@ __global__ __launch_bounds__(256, HD <= 40 ? 3 : (HD <= 80 ? 2 : 1)) void attn_k
     if (MORE) {
       store_v((it + 1) & 1);
       if (it + 2 < nt) store_k(it & 1);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) s_cur[t] = s_nxt[t];
     }
     __syncthreads();
   };
-  for (int it = 0; it + 1 < nt; ++it) tile_step(std::true_type{}, it);
-  if (nt > 0) tile_step(std::false_type{}, nt - 1);
+  {
+    int it = 0;
+    for (; it + 2 < nt; it += 2) {     // two tiles per trip so that the current / next score registers swap by name
+      tile_step(std::true_type{}, it, s_a, s_b);
+      tile_step(std::true_type{}, it + 1, s_b, s_a);
+    }
+    if (it + 2 == nt) {
+      tile_step(std::true_type{}, it, s_a, s_b);
+      tile_step(std::false_type{}, it + 1, s_b, s_a);
+    } else if (it + 1 == nt) {
+      tile_step(std::false_type{}, it, s_a, s_b);
+    }
+  }
 
   // ---- normalise and store: lane owns row q0+l31, d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
   float l_tot;
@@ -376,13 +419,22 @@ __global__ __launch_bounds__(256, HD <= 40 ? 3 : (HD <= 80 ? 2 : 1)) void attn_k
 }
 
 template <typename T>
-static int launch_attn(const AttnArgs& a, int hd, hipStream_t st) {
+static int launch_attn(const AttnArgs& a, int hd, bool pre, hipStream_t st) {
   dim3 grid(a.batch * a.heads * a.nqb), block(256);
-  switch (hd) {
-    case 40: hipLaunchKernelGGL((attn_kernel<T, 40>), grid, block, 0, st, a); break;
-    case 80: hipLaunchKernelGGL((attn_kernel<T, 80>), grid, block, 0, st, a); break;
-    case 160: hipLaunchKernelGGL((attn_kernel<T, 160>), grid, block, 0, st, a); break;
-    default: return -22;
+  if (pre) {
+    switch (hd) {
+      case 40: hipLaunchKernelGGL((attn_kernel<T, 40, true>), grid, block, 0, st, a); break;
+      case 80: hipLaunchKernelGGL((attn_kernel<T, 80, true>), grid, block, 0, st, a); break;
+      case 160: hipLaunchKernelGGL((attn_kernel<T, 160, true>), grid, block, 0, st, a); break;
+      default: return -22;
+    }
+  } else {
+    switch (hd) {
+      case 40: hipLaunchKernelGGL((attn_kernel<T, 40, false>), grid, block, 0, st, a); break;
+      case 80: hipLaunchKernelGGL((attn_kernel<T, 80, false>), grid, block, 0, st, a); break;
+      case 160: hipLaunchKernelGGL((attn_kernel<T, 160, false>), grid, block, 0, st, a); break;
+      default: return -22;
+    }
   }
   HALLO_CHECK_LAUNCH();
   return 0;
@@ -488,8 +540,8 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
   a.rs_hdiv = d->o_rowscale_head_div > 0 ? d->o_rowscale_head_div : d->heads;
   a.rs_stride = d->o_rowscale_stride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (d->dtype == DT_F16) return launch_attn<_Float16>(a, d->head_dim, st);
-  if (d->dtype == DT_BF16) return launch_attn<__bf16>(a, d->head_dim, st);
+  if (d->dtype == DT_F16) return launch_attn<_Float16>(a, d->head_dim, d->q_prescaled != 0, st);
+  if (d->dtype == DT_BF16) return launch_attn<__bf16>(a, d->head_dim, d->q_prescaled != 0, st);
   return -22;
 }
 

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         if (bias && p.bias_per_row) v += to_f32(bias[m]);
         if (bias2) v += to_f32(bias2[(long)(m / p.bias2_rpg) * p.bias2_ld + n]);
         if (p.rowscale) v *= p.rowscale[m];
-        v *= p.alpha;
+        v *= (n < p.lead_cols) ? p.alpha * p.lead_alpha : p.alpha;
         if (res) v += to_f32(res[(long)m * p.ldr + n]);
         if (p.act == ACT_SILU) v = silu_f(v);
         else if (p.act == ACT_RELU) v = fmaxf(v, 0.0f);
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 ? 3 : 4)) void ge
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += t8[j];
           }
-          const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+          const float rs = (p.rowscale ? p.rowscale[m] * p.alpha : p.alpha) * ((n < p.lead_cols) ? p.lead_alpha : 1.0f);
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] *= rs;
           if (use_res) {
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] += to_f32(b2[j]);
   }
-  const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+  const float rs = (p.rowscale ? p.rowscale[m] * p.alpha : p.alpha) * ((n < p.lead_cols) ? p.lead_alpha : 1.0f);
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] *= rs;
   if (res) {
@@ -803,7 +803,7 @@ extern "C" int hallo_gemm(const hallo_gemm_desc* d, void* stream) {
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K & 7)) return -22;
   if (d->batch < 1) return -22;
   if ((d->lda & 7) || (d->ldb & 7)) return -22;
-  if (d->geglu && (d->rowscale || d->residual || d->bias2 || d->out_f32 || d->bias_per_row)) return -22;
+  if (d->geglu && (d->rowscale || d->residual || d->bias2 || d->out_f32 || d->bias_per_row || d->lead_cols > 0)) return -22;
   GemmArgs a;
   a.A = d->A; a.B = d->B; a.C = d->C;
   a.M = d->M; a.N = d->N; a.K = d->K;
@@ -815,6 +815,8 @@ extern "C" int hallo_gemm(const hallo_gemm_desc* d, void* stream) {
   a.rowscale = d->rowscale;
   a.residual = d->residual; a.ldr = d->ldr; a.sR = d->stride_r;
   a.alpha = d->alpha; a.act = d->act; a.out_f32 = d->out_f32;
+  a.lead_cols = d->lead_cols > 0 ? d->lead_cols : 0; a.lead_alpha = d->lead_cols > 0 ? d->lead_alpha : 1.0f;
+  if (a.lead_cols & 7) return -22;
   a.tiles_m = (d->M + BM - 1) / BM;
   a.tiles_n = d->geglu ? (d->N + 63) / 64 : (d->N + BN - 1) / BN;
   a.H = a.W = a.Cin = a.OH = a.OW = a.stride = a.pad_t = a.pad_l = a.upsample = 0;
@@ -842,6 +844,7 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
   a.rowscale = nullptr;
   a.residual = d->residual; a.ldr = d->ldr > 0 ? d->ldr : d->Cout; a.sR = 0;
   a.alpha = d->alpha; a.act = d->act; a.out_f32 = 0;
+  a.lead_cols = 0; a.lead_alpha = 1.0f;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW;

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] += t8[j];
         }
-        const float rs = p.rowscale ? p.rowscale[m] * p.alpha : p.alpha;
+        const float rs = (p.rowscale ? p.rowscale[m] * p.alpha : p.alpha) * ((n < p.lead_cols) ? p.lead_alpha : 1.0f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] *= rs;
         if (use_res) {

@@ -18,6 +18,8 @@ struct GemmArgs {
   const void* residual;     // [M,N] (ld = ldr) or null
   long ldr, sR;
   float alpha;
+  int lead_cols;            // output columns n < lead_cols get an extra factor lead_alpha (the q part of a fused q|k|v
+  float lead_alpha;         // projection carries softmax scale * log2(e) so that the attention kernel can exp2 raw scores)
   int act;
   int out_f32;
   int tiles_n, tiles_m;

@@ -39,6 +39,8 @@ class GemmDesc(C.Structure):
         ("dtype", C.c_int),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_int64),
+        ("lead_cols", C.c_int),
+        ("lead_alpha", C.c_float),
     ]
 
 
@@ -76,6 +78,7 @@ class AttnDesc(C.Structure):
         ("scale", C.c_float),
         ("dtype", C.c_int),
         ("o_rowscale", C.c_void_p), ("o_rowscale_head_div", C.c_int), ("o_rowscale_stride", C.c_int64),
+        ("q_prescaled", C.c_int),
     ]
 
 

@@ -72,7 +72,7 @@ class BasicTransformerBlock(nn.Module):
         nh = self.norm1.run(x)
         bank_out.append(nh)
         _, q, k, v = self.attn1.qkv(nh)
-        a = ops.attention(q, k, v, self.attn1.heads)
+        a = ops.attention(q, k, v, self.attn1.heads, q_prescaled=True)
         x = self.attn1.out(a, residual=x)
         nh = self.norm2.run(x)
         # mutual_self_attention.py:341-349: `encoder_hidden_states.repeat(tmp, 1, 1)` TILES the face tokens
@@ -80,8 +80,8 @@ class BasicTransformerBlock(nn.Module):
         k2, v2 = self.attn2.kv(enc)
         rep = n // enc.shape[0]
         k2, v2 = k2.repeat(rep, 1, 1), v2.repeat(rep, 1, 1)
-        q2 = self.attn2.to_q.run(nh.view(-1, nh.shape[-1])).view(n, -1, self.attn2.inner)
-        a = ops.attention(q2, k2, v2, self.attn2.heads)
+        q2 = self.attn2.q(nh.view(-1, nh.shape[-1])).view(n, -1, self.attn2.inner)
+        a = ops.attention(q2, k2, v2, self.attn2.heads, q_prescaled=True)
         x = self.attn2.out(a, residual=x)
         return self.ff.run(self.norm3.run(x), residual=x)
 
@@ -116,7 +116,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         # 3-D tensor tiles the batch axis, mutual_self_attention.py:235-247); with CFG the first half of the
         # rows (uncond) skips the bank segment (:264-284).
         a = ops.attention(q, k, v, a1.heads, k2=k2, v2=v2, kv2_batch_div=1, kv2_batch_mod=b,
-                          kv2_first_batch=(n // 2 if do_cfg else 0))
+                          kv2_first_batch=(n // 2 if do_cfg else 0), q_prescaled=True)
         x = a1.out(a, residual=x)
 
         a2 = self.attn2
@@ -129,8 +129,8 @@ class TemporalBasicTransformerBlock(nn.Module):
             return ex(kf), ex(vf)
         kf, vf = cache.get(self, "face_kv", face_kv)
         nh = self.norm2.run(x)
-        q2 = a2.to_q.run(nh.view(n * L, Cd)).view(n, L, Cd)
-        a = ops.attention(q2, kf, vf, a2.heads)
+        q2 = a2.q(nh.view(n * L, Cd)).view(n, L, Cd)
+        a = ops.attention(q2, kf, vf, a2.heads, q_prescaled=True)
         x = a2.out(a, residual=x)
         return self.ff.run(self.norm3.run(x), residual=x)
 
@@ -178,7 +178,7 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
         n, L, D = x.shape
         nh = self.norm1.run(x)
         _, q, k, v = self.attn1.qkv(nh)
-        a = ops.attention(q, k, v, self.attn1.heads)
+        a = ops.attention(q, k, v, self.attn1.heads, q_prescaled=True)
         x = self.attn1.out(a, residual=x)
 
         def audio_kv():
@@ -202,10 +202,11 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
         bias_c = cache.get(self, "bias_c", lambda: (torch.tensor(ms, device=x.device)[:, None] * self.bz3).sum(0).to(x.dtype))
 
         nh = self.norm2.run(x)
-        q3 = ops.gemm(nh.view(n * L, D), self.w_q3).view(n, L, 3 * D)
+        q3 = ops.gemm(nh.view(n * L, D), self.w_q3, alpha=ops.q_scale(self.attn2_0.dim_head)).view(n, L, 3 * D)
         # three branches x heads as one attention launch; output rows pre-scaled by motion_scale[i] * mask_i
         # (attention.py:853-903) and written straight into the fused GEMM's A operand
         ops.attention(q3, kv3[:, :, :3 * D], kv3[:, :, 3 * D:], 3 * self.attn2_0.heads,
-                      out=A.view(n, L, 3 * D + 8)[:, :, :3 * D], rowscale=msmask, rowscale_head_div=self.attn2_0.heads)
+                      out=A.view(n, L, 3 * D + 8)[:, :, :3 * D], rowscale=msmask, rowscale_head_div=self.attn2_0.heads,
+                      q_prescaled=True)
         x = ops.gemm(A, self.w_fused, bias_c, residual=x.view(n * L, D)).view(n, L, D)
         return self.ff.run(self.norm3.run(x), residual=x)

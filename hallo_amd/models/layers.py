@@ -175,9 +175,12 @@ class Attention(nn.Module):
 
     # -- fused projections -----------------------------------------------------------------
     def qkv(self, x):
-        """x [N, L, C] -> fused [N, L, 3*inner]; q/k/v are column slices (views)."""
+        """x [N, L, C] -> fused [N, L, 3*inner]; q/k/v are column slices (views).  The q columns leave the GEMM
+        multiplied by head_dim^-0.5 * log2(e) (fp32, before the single rounding to the storage type):
+        hallo_attention(q_prescaled=True) then exponentiates raw scores."""
         N, L, Cd = x.shape
-        y = ops.gemm(x.view(N * L, Cd), self.w_qkv, self.b_qkv).view(N, L, 3 * self.inner)
+        y = ops.gemm(x.view(N * L, Cd), self.w_qkv, self.b_qkv, lead_cols=self.inner,
+                     lead_alpha=ops.q_scale(self.dim_head)).view(N, L, 3 * self.inner)
         i = self.inner
         return y, y[:, :, :i], y[:, :, i:2 * i], y[:, :, 2 * i:]
 
@@ -186,6 +189,10 @@ class Attention(nn.Module):
         N, L, Cd = ctx.shape
         y = ops.gemm(ctx.reshape(N * L, Cd), self.w_kv, self.b_kv).view(N, L, 2 * self.inner)
         return y[:, :, : self.inner], y[:, :, self.inner:]
+
+    def q(self, x2d):
+        """to_q with the softmax scale folded in (see qkv)."""
+        return self.to_q.run(x2d, alpha=ops.q_scale(self.dim_head))
 
     def out(self, a, residual=None, **epi):
         """to_out.0 (+ residual) on a [N, L, inner]."""

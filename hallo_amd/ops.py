@@ -55,7 +55,7 @@ def _workspace(device):
 
 
 def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, act=ACT_NONE, geglu=False,
-         bias2=None, bias2_rows_per_group=0, out_f32=False, bias_per_row=False):
+         bias2=None, bias2_rows_per_group=0, out_f32=False, bias_per_row=False, lead_cols=0, lead_alpha=1.0):
     """out[M,N] = act(alpha * rowscale * (a[M,K] @ w[N,K]^T + bias) + residual).
 
     a may be a 2-D view with arbitrary row stride (last dim contiguous).  geglu: w is [2N,K]."""
@@ -87,6 +87,7 @@ def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, 
     else:
         d.residual, d.ldr = None, 0
     d.alpha, d.act, d.geglu, d.out_f32 = float(alpha), act, 1 if geglu else 0, 1 if out_f32 else 0
+    d.lead_cols, d.lead_alpha = int(lead_cols), float(lead_alpha)
     d.dtype = dtype_code(a.dtype)
     ws = _workspace(a.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), SPLITK_WS_BYTES
@@ -109,6 +110,7 @@ def gemm_batched(a, w, out, *, out_f32=False, alpha=1.0, bias=None, bias_per_row
     d.bias_per_row = 1 if bias_per_row else 0
     d.bias2, d.bias2_rows_per_group, d.bias2_ld, d.rowscale, d.residual, d.ldr = None, 0, 0, None, None, 0
     d.alpha, d.act, d.geglu, d.out_f32 = float(alpha), ACT_NONE, 0, 1 if out_f32 else 0
+    d.lead_cols, d.lead_alpha = 0, 1.0
     d.dtype = dtype_code(a.dtype)
     d.workspace, d.workspace_bytes = None, 0
     _l.check(_l.load().hallo_gemm(C.byref(d), _stream()), "hallo_gemm(batched)")
@@ -152,7 +154,7 @@ def conv3x3(x, w, bias, n_img, H, W, *, stride=1, pad_t=1, pad_l=1, out_hw=None,
 
 
 def attention(q, k1, v1, heads, *, k2=None, v2=None, kv2_batch_div=1, kv2_batch_mod=0, kv2_first_batch=0, out=None,
-              scale=None, rowscale=None, rowscale_head_div=0):
+              scale=None, rowscale=None, rowscale_head_div=0, q_prescaled=False):
     """softmax(q k^T * scale) v over up to two key/value segments.
 
     q [B, Lq, C], k1/v1 [B, Lkv1, C], k2/v2 [B2, Lkv2, C] are views with contiguous last dim
@@ -183,6 +185,7 @@ def attention(q, k1, v1, heads, *, k2=None, v2=None, kv2_batch_div=1, kv2_batch_
     d.kv2_batch_div, d.kv2_batch_mod, d.kv2_first_batch = kv2_batch_div, kv2_batch_mod, kv2_first_batch
     d.scale = float(scale if scale is not None else hd ** -0.5)
     d.dtype = dtype_code(q.dtype)
+    d.q_prescaled = 1 if q_prescaled else 0
     if rowscale is not None:
         # fp32 [G, B*Lq]: head h is scaled by row h // rowscale_head_div of it (G = heads // rowscale_head_div groups)
         assert rowscale.dtype == torch.float32 and rowscale.is_contiguous()
@@ -193,6 +196,14 @@ def attention(q, k1, v1, heads, *, k2=None, v2=None, kv2_batch_div=1, kv2_batch_
         d.o_rowscale, d.o_rowscale_head_div, d.o_rowscale_stride = None, 0, 0
     _l.check(_l.load().hallo_attention(C.byref(d), _stream()), "hallo_attention")
     return out
+
+
+LOG2E = 1.4426950408889634
+
+
+def q_scale(head_dim):
+    """The factor a q projection must carry for hallo_attention(q_prescaled=True): head_dim^-0.5 * log2(e)."""
+    return head_dim ** -0.5 * LOG2E
 
 
 def temporal_attention(qkv, B, F, HW, Cdim, heads, *, out=None, scale=None):

@@ -74,6 +74,12 @@ typedef struct hallo_gemm_desc {
   int dtype;
   void* workspace;           /* optional fp32 scratch for split-K partial sums (small grids with long K); may be null */
   int64_t workspace_bytes;
+  /* ABI v2: output columns n < lead_cols (multiple of 8; 0 = none) are multiplied by lead_alpha on top of alpha /
+   * rowscale, before the residual add.  Used for the q part of Attention.to_q / fused q|k|v projections: q leaves the
+   * GEMM already scaled by head_dim^-0.5 * log2(e) (one rounding, like the reference's own rounding of q), and
+   * hallo_attention(q_prescaled = 1) exponentiates raw scores. */
+  int lead_cols;
+  float lead_alpha;
 } hallo_gemm_desc;
 int hallo_gemm(const hallo_gemm_desc* d, void* stream);
 
@@ -139,6 +145,7 @@ typedef struct hallo_attn_desc {
   const float* o_rowscale;
   int o_rowscale_head_div;      /* <= 0: all heads share one scale vector */
   int64_t o_rowscale_stride;
+  int q_prescaled;              /* 1: q already carries scale * log2(e) (hallo_gemm lead_alpha); `scale` is ignored */
 } hallo_attn_desc;
 int hallo_attention(const hallo_attn_desc* d, void* stream);
 

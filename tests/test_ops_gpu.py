@@ -341,6 +341,34 @@ def test_attention_audio_branches_one_launch(dtype, hd, L, report):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd,Lq,Lkv", [(40, 300, 700), (40, 64, 4), (80, 200, 333), (160, 100, 64)])
+def test_attention_prescaled_q(dtype, hd, Lq, Lkv, report):
+    """q produced by a fused q|k|v GEMM whose q columns carry head_dim^-0.5 * log2(e) (hallo_gemm lead_alpha),
+    consumed by hallo_attention(q_prescaled=1); compared with SDPA on the unscaled projection.  The extra error
+    source is one rounding of the scaled q instead of the unscaled q."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(hd * 31 + Lq + Lkv)
+    B, H = 2, 8
+    Cd = H * hd
+    x = _rand((B * Lq, Cd), dtype, g)
+    ctx = _rand((B * Lkv, Cd), dtype, g)
+    w = _rand((3 * Cd, Cd), dtype, g, Cd ** -0.5)
+    qkv_ref = ops.gemm(x, w).view(B, Lq, 3 * Cd)                     # unscaled projection (reference rounding)
+    qkv = ops.gemm(x, w, lead_cols=Cd, lead_alpha=ops.q_scale(hd)).view(B, Lq, 3 * Cd)
+    assert torch.equal(qkv[:, :, Cd:], qkv_ref[:, :, Cd:]), "lead_alpha must leave the k|v columns untouched"
+    kv = ops.gemm(ctx, w[Cd:]).view(B, Lkv, 2 * Cd)
+    k, v = kv[:, :, :Cd], kv[:, :, Cd:]
+    out = ops.attention(qkv[:, :, :Cd], k, v, H, q_prescaled=True)
+    _check(f"attn_prescaled[{hd},{Lq},{Lkv}]", out, ops_ref.sdpa(qkv_ref[:, :, :Cd], k, v, H), dtype, report)
+    if hd == 40:   # force the rescale path of the pad-column variant: one key far above the rest, late
+        k2 = k.clone()
+        k2[:, Lkv - 3] = qkv_ref[:, 5, :Cd] * 3.0
+        out = ops.attention(qkv[:, :, :Cd], k2, v, H, q_prescaled=True)
+        _check(f"attn_prescaled_spike[{hd},{Lq},{Lkv}]", out, ops_ref.sdpa(qkv_ref[:, :, :Cd], k2, v, H), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_forced_rescale(dtype, report):
     """One key far above the rest late in the sequence forces the online-softmax rescale path."""
     from hallo_amd import ops
