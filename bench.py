@@ -50,12 +50,29 @@ class OpProfiler:
             fl, by = cost(a, k, r)
             shp = tuple(tuple(t.shape) for t in a[:3] if torch.is_tensor(t)) + ((("geglu",),) if k.get("geglu") else ()) \
                 + ((("res",),) if k.get("residual") is not None else ()) + ((("k2", tuple(k["k2"].shape)),) if k.get("k2") is not None else ())
-            self.records.append((name, s, e, fl, by, shp))
+            self.records.append((name, s, e, fl, by, shp, self._symbol(name, a, k)))
             return r
         return w
 
-    def install(self):
+    def _symbol(self, name, a, k):
+        """The kernel SYMBOL a launch ran (as rocprofv3 --stats names it), so that bench rates can be checked against
+        the committed profile per symbol.  GEMM / conv: asked from the library (the auto rule picks the kernel)."""
         from hallo_amd import ops
+        dt = "__bf16" if self.dtype == torch.bfloat16 else "_Float16"
+        if name in ("gemm", "conv3x3"):
+            c = ops.get_option("last_gemm_kernel")
+            kern, mode, sub = c // 100, (c // 10) % 10, c % 10
+            if kern == 1:
+                return "gemm_kernel<%s,%s,%s>" % (dt, "true" if mode == 1 else "false", "true" if mode == 2 else "false")
+            return "gemm%d_kernel<%s,%d,%d>" % (kern, dt, mode, sub)
+        if name == "attention":
+            hd = a[0].shape[-1] // a[3]
+            return "attn_kernel<%s,%d,%s>" % (dt, hd, "true" if k.get("q_prescaled") else "false")
+        return name
+
+    def install(self, dtype=torch.bfloat16):
+        from hallo_amd import ops
+        self.dtype = dtype
         es = 2  # bytes per element (fp16 / bf16)
 
         def c_gemm(a, k, r):
@@ -121,22 +138,19 @@ class OpProfiler:
         torch.cuda.synchronize()
         fam = {}
         self.by_shape = {}
-        for name, s, e, fl, by, shp in self.records:
-            d2 = self.by_shape.setdefault((name, shp), dict(ms=0.0, flop=0.0, bytes=0.0, launches=0))
+        self.by_symbol = {}
+        for name, s, e, fl, by, shp, sym in self.records:
             ms_ = s.elapsed_time(e)
-            d2["ms"] += ms_
-            d2["flop"] += fl
-            d2["bytes"] += by
-            d2["launches"] += 1
-        for name, s, e, fl, by, shp in self.records:
-            d = fam.setdefault(name, dict(ms=0.0, flop=0.0, bytes=0.0, launches=0))
-            d["ms"] += s.elapsed_time(e)
-            d["flop"] += fl
-            d["bytes"] += by
-            d["launches"] += 1
-        for d in fam.values():
-            d["tflops"] = d["flop"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-            d["gbs"] = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+            for table, key in ((self.by_shape, (name, shp)), (fam, name), (self.by_symbol, sym)):
+                d = table.setdefault(key, dict(ms=0.0, flop=0.0, bytes=0.0, launches=0))
+                d["ms"] += ms_
+                d["flop"] += fl
+                d["bytes"] += by
+                d["launches"] += 1
+        for table in (fam, self.by_symbol):
+            for d in table.values():
+                d["tflops"] = d["flop"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+                d["gbs"] = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
         return fam
 
 
@@ -353,7 +367,7 @@ def main():
 
     if rank == 0 and not args.no_profile:
         prof = OpProfiler()
-        prof.install()
+        prof.install(dtype)
         run(inputs[-1])
         fam = prof.summary()
         prof.remove()
@@ -372,16 +386,33 @@ def main():
                               "gbs": round(d["gbs"], 1)} for k, d in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         out["kernel_ms_per_clip"] = round(tot_ms, 1)
         out["algorithmic_tflop_per_clip"] = round(tot_flop / 1e12, 1)
-        dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
-        name, d = dom
-        if name in ("gemm", "conv3x3", "attention", "gemm_batched"):
+        # roofline of the dominant kernel SYMBOL (the name rocprofv3 --kernel-trace --stats reports; the committed summary
+        # profiles/r1_bench_kernel_stats.csv is of this same command).  achieved = algorithmic flop (or bytes) of that
+        # symbol's launches / their summed duration, both from events on the launch stream in this run.
+        out["kernel_symbols"] = {k: {"ms": round(d["ms"], 2), "launches": d["launches"], "tflops": round(d["tflops"], 1),
+                                     "gbs": round(d["gbs"], 1), "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1)}
+                                 for k, d in sorted(prof.by_symbol.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+        name, d = max(prof.by_symbol.items(), key=lambda kv: kv[1]["ms"])
+        traffic = None
+        try:    # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py), if committed
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            t = tj.get(name.split("<")[0])
+            if t:
+                traffic = {"fetch_bytes_per_launch": round(t["fetch_bytes_per_launch"]), "write_bytes_per_launch": round(t["write_bytes_per_launch"]),
+                           "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "source": tj.get("_source", "profiles/r1_pmc_traffic.json")}
+        except Exception:
+            pass
+        mfma_bound = name.startswith(("gemm", "attn_kernel"))
+        if mfma_bound:
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(d["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                               "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_clip": d["launches"]}
+                               "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                               "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_clip": d["launches"],
+                               "share_of_kernel_time": round(d["ms"] / tot_ms, 3)}
         else:
             out["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(d["gbs"], 1), "peak": PEAK_HBM_GBS,
-                               "unit": "GB/s", "frac": round(d["gbs"] / PEAK_HBM_GBS, 4), "traffic": None,
-                               "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_clip": d["launches"]}
+                               "unit": "GB/s", "frac": round(d["gbs"] / PEAK_HBM_GBS, 4), "traffic": traffic,
+                               "avg_launch_ms": round(d["ms"] / d["launches"], 4), "launches_per_clip": d["launches"],
+                               "share_of_kernel_time": round(d["ms"] / tot_ms, 3)}
         if "attention" in fam:
             a = fam["attention"]
             out["attention"] = {"hbm_gbs": round(a["gbs"], 1), "hbm_frac": round(a["gbs"] / PEAK_HBM_GBS, 4),

@@ -1,0 +1,92 @@
+"""Sliding-window video driver: the caller of the hot path and the uint8 output conversion (row 3).
+
+Reference: scripts/inference.py:95-114 (`process_audio_emb`), :265-347 (the clip loop of `inference_process`),
+hallo/utils/util.py:297-312 (`tensor_to_video`'s [0, 1] -> uint8 conversion).
+
+Same sequential semantics as the reference -- clip t+1's two motion frames are the last two decoded frames of clip t,
+one CPU generator seeded once feeds every clip's latents -- with the device doing the carrying:
+  * the 5-frame audio context window is one index gather (the reference builds it with T x 5 Python-level stacks);
+  * decoded frames stay in HBM: the motion frames of the next clip are sliced from the device tensor, the frames are
+    converted to uint8 on the device (4x fewer bytes) and copied to pinned host memory asynchronously, so the D2H of
+    clip t overlaps the denoising of clip t+1 (the reference does a blocking fp32 `.cpu()` per clip).
+"""
+import torch
+
+from .. import ops
+
+
+def process_audio_emb(audio_emb):
+    """(T, ...) -> (T, 5, ...): frame i sees frames i-2 .. i+2, indices clamped to [0, T-1]
+    (scripts/inference.py:95-114)."""
+    T = audio_emb.shape[0]
+    idx = (torch.arange(T, device=audio_emb.device)[:, None] + torch.arange(-2, 3, device=audio_emb.device)[None, :])
+    return audio_emb[idx.clamp_(0, T - 1)]
+
+
+def frames_to_uint8(video):
+    """(3, F, H, W) fp32 in [0, 1] -> uint8 (F, H, W, 3) = np.clip(x * 255, 0, 255).astype(np.uint8)
+    (hallo/utils/util.py:308-312).  Device tensors go through the HIP kernel (byte-exact)."""
+    Cc, Fr, H, W = video.shape
+    x = video.permute(1, 0, 2, 3).reshape(Fr, Cc, H * W).contiguous()
+    return ops.frames_to_uint8(x).view(Fr, H, W, Cc)
+
+
+@torch.no_grad()
+def generate_video(pipeline, audioproj, source_image_pixels, source_image_face_region, source_image_face_emb,
+                   full_mask, face_mask, lip_mask, audio_emb, *, clip_length=16, n_motion_frames=2, img_size=(512, 512),
+                   inference_steps=40, cfg_scale=3.5, motion_scale=None, audio_length=None, seed=42,
+                   output="float", on_clip=None):
+    """The clip loop of scripts/inference.py:265-343.
+
+    source_image_pixels (3, H, W) in [-1, 1]; source_image_face_region (3, H, W); source_image_face_emb (512,);
+    full/face/lip_mask: lists of 4 tensors (1, (H/8/2^l)^2); audio_emb (T, 12, 768) raw wav2vec hidden-state stack.
+    Returns (3, audio_length, H, W) fp32 on the CPU (output="float", the reference's tensor) or uint8
+    (audio_length, H, W, 3) (output="uint8", what tensor_to_video feeds the encoder)."""
+    dev = source_image_pixels.device
+    audio_emb = process_audio_emb(audio_emb)
+    src = source_image_pixels.unsqueeze(0)
+    face_region = source_image_face_region.unsqueeze(0)
+    face_emb = torch.as_tensor(source_image_face_emb).reshape(1, -1)
+    full_mask = [m.repeat(clip_length, 1) for m in full_mask]
+    face_mask = [m.repeat(clip_length, 1) for m in face_mask]
+    lip_mask = [m.repeat(clip_length, 1) for m in lip_mask]
+    times = audio_emb.shape[0] // clip_length
+    if audio_length is None:
+        audio_length = times * clip_length
+    generator = torch.Generator().manual_seed(seed)       # ONE CPU stream for all clips (inference.py:289)
+    on_gpu = dev.type == "cuda"
+    results = []
+    prev = None                                            # (1, 3, F, H, W) of the previous clip, on `dev`
+    for t in range(times):
+        if prev is None:
+            motion = src.repeat(n_motion_frames, 1, 1, 1)                       # first clip: the source image
+        else:
+            motion = prev[0].permute(1, 0, 2, 3)[-n_motion_frames:] * 2.0 - 1.0   # last frames of clip t-1, back to [-1, 1]
+        ref_img = torch.cat([src, motion.to(src.dtype)], dim=0).unsqueeze(0)
+        audio_tensor = audioproj(audio_emb[t * clip_length:(t + 1) * clip_length].unsqueeze(0))
+        out = pipeline(ref_image=ref_img, audio_tensor=audio_tensor, face_emb=face_emb, face_mask=face_region,
+                       pixel_values_full_mask=full_mask, pixel_values_face_mask=face_mask,
+                       pixel_values_lip_mask=lip_mask, width=img_size[0], height=img_size[1], video_length=clip_length,
+                       num_inference_steps=inference_steps, guidance_scale=cfg_scale, generator=generator,
+                       motion_scale=motion_scale, **({"output_type": "device"} if on_gpu else {}))
+        prev = out.videos
+        if output == "uint8" and on_gpu:
+            u8 = frames_to_uint8(prev[0])
+            host = torch.empty(u8.shape, dtype=torch.uint8).pin_memory()
+            host.copy_(u8, non_blocking=True)              # overlaps the next clip's denoising
+            results.append(host)
+        elif on_gpu:
+            host = torch.empty(prev.shape, dtype=prev.dtype).pin_memory()
+            host.copy_(prev, non_blocking=True)
+            results.append(host)
+        else:
+            results.append(prev)
+        if on_clip is not None:
+            on_clip(t, times)
+    if on_gpu:
+        torch.cuda.current_stream().synchronize()
+    if output == "uint8" and on_gpu:
+        return torch.cat(results, dim=0)[:audio_length]
+    if output == "uint8":
+        raise ops._l.HalloLibraryError("uint8 output runs through hallo_frames_to_uint8 on the GPU; there is no CPU path")
+    return torch.cat(results, dim=2).squeeze(0)[:, :audio_length]

@@ -66,8 +66,23 @@ template <typename T> __device__ __forceinline__ typename Vec<T>::v8 zero8() {
   return z;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu_f(float x) {   // x * sigmoid(x): v_exp + v_rcp (1 ulp), no IEEE division sequence
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+// GELU (erf form, diffusers GEGLU: hallo/models/attention.py:601,905).  erf by Abramowitz-Stegun 7.1.26
+// (|error| < 1.5e-7, far below the fp16 / bf16 output rounding): branch-free, 14 VALU ops against ~35 and a divergent
+// branch for ocml's erff -- the GEGLU epilogue of the K = 320 feed-forward GEMMs is VALU-bound on this function.
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  const float erf_abs = __builtin_fmaf(-p * t, e, 1.0f);
+  return 0.5f * x * (1.0f + __builtin_copysignf(erf_abs, x));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

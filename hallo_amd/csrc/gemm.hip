@@ -680,6 +680,9 @@ static int g_gemm_variant = 6;
 static int g_split_k = 1;        // 0: never split K, 1: auto
 static int g_conv_fast = 1;      // 0: always use the general (per-thread tap) conv gather
 static int g_v3_min_tiles = 192; // auto: smallest grid (workgroups, 1 per CU) worth the big-tile kernel
+// Kernel picked by the last hallo_gemm / hallo_conv3x3_nhwc call, for per-symbol profiling (bench.py):
+// 100 * kernel (1 gemm_kernel, 2 gemm2_kernel, 3 gemm3_kernel) + 10 * mode (0 gemm, 1 conv, 2 geglu) + stages / TM
+static int g_last_kernel = 0;
 
 
 template <typename T>
@@ -732,6 +735,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
         a.splits = (nk + a.nk_per_split - 1) / a.nk_per_split;
         a.slab = reinterpret_cast<float*>(ws);
       }
+      g_last_kernel = 300 + 10 * (geglu ? 2 : (conv ? 1 : 0)) + tm;
       launch_gemm3<T>(a, geglu ? 2 : (conv ? 1 : 0), tm, batch, st);
       HALLO_CHECK_LAUNCH();
       if (a.splits > 1) {
@@ -762,6 +766,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     }
   }
   dim3 grid(tiles, a.splits, batch), block(256);
+  g_last_kernel = (v == 0 ? 100 : 200) + 10 * (geglu ? 2 : (conv ? 1 : 0)) + (v == 0 ? 0 : v);
   if (v == 0) {
     if (geglu) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, st, a);
     else if (conv) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, st, a);
@@ -854,6 +859,15 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (d->dtype == DT_F16) return launch_gemm<_Float16>(a, true, false, 1, d->workspace, d->workspace_bytes, st);
   if (d->dtype == DT_BF16) return launch_gemm<__bf16>(a, true, false, 1, d->workspace, d->workspace_bytes, st);
+  return -22;
+}
+
+extern "C" int hallo_get_option(const char* name) {
+  if (!name) return -22;
+  if (!strcmp(name, "gemm_variant")) return g_gemm_variant;
+  if (!strcmp(name, "split_k")) return g_split_k;
+  if (!strcmp(name, "v3_min_tiles")) return g_v3_min_tiles;
+  if (!strcmp(name, "last_gemm_kernel")) return g_last_kernel;
   return -22;
 }
 

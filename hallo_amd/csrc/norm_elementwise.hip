@@ -370,6 +370,23 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const T* __restri
 }
 
 // ------------------------------------------------------------------------------------------
+// Output path: planar fp32 frames [F, 3, H*W] in [0, 1] -> interleaved uint8 frames [F, H*W, 3]
+// = np.clip(x * 255, 0, 255).astype(np.uint8) of tensor_to_video (hallo/utils/util.py:308-312): fp32 multiply,
+// clamp, truncation toward zero -- bit-exact with the numpy expression on the same fp32 input.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frames_to_uint8_kernel(const float* __restrict__ x, uint8_t* __restrict__ y,
+                                                              int C, long HW) {
+  const long f = blockIdx.y;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  for (int c = 0; c < C; ++c) {
+    float v = __fmul_rn(x[(f * C + c) * HW + p], 255.0f);
+    v = fminf(fmaxf(v, 0.0f), 255.0f);          // NaN -> 0 like np.clip + astype on this platform is undefined; inputs are clamped
+    y[(f * HW + p) * C + c] = (uint8_t)v;       // float -> integer conversion truncates toward zero
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Timestep embedding: [cos | sin] (flip_sin_to_cos=True, downscale_freq_shift=0).
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -494,6 +511,14 @@ extern "C" int hallo_layernorm(const void* x, void* y, const void* gamma, const 
   if (dtype == DT_F16) return launch_layernorm<_Float16>(x, y, gamma, beta, pe, rows, C, eps, rpp, plen, st);
   if (dtype == DT_BF16) return launch_layernorm<__bf16>(x, y, gamma, beta, pe, rows, C, eps, rpp, plen, st);
   return -22;
+}
+
+extern "C" int hallo_frames_to_uint8(const float* x, uint8_t* y, int frames, int channels, int64_t hw, void* stream) {
+  if (!x || !y || frames <= 0 || channels <= 0 || channels > 4 || hw <= 0) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(frames_to_uint8_kernel, dim3((unsigned)((hw + 255) / 256), frames), dim3(256), 0, st, x, y, channels, (long)hw);
+  HALLO_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int hallo_softmax_rows(const float* x, void* y, int rows, int cols, float scale, int dtype, void* stream) {

@@ -87,6 +87,7 @@ class AttnDesc(C.Structure):
 SYMBOLS = {
     "hallo_abi_version": (C.c_int, []),
     "hallo_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "hallo_get_option": (C.c_int, [C.c_char_p]),
     "hallo_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "hallo_conv3x3_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "hallo_attention": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
@@ -104,6 +105,7 @@ SYMBOLS = {
                                      C.c_void_p]),
     "hallo_nhwc_to_nchw_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float,
                                          C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "hallo_frames_to_uint8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "hallo_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hallo_cfg_ddim_step": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),

@@ -41,6 +41,10 @@ def set_option(name, value):
     _l.check(_l.load().hallo_set_option(name.encode(), int(value)), f"hallo_set_option({name})")
 
 
+def get_option(name):
+    return _l.load().hallo_get_option(name.encode())
+
+
 _splitk_ws = {}
 SPLITK_WS_BYTES = 128 << 20
 
@@ -311,3 +315,15 @@ def cfg_ddim_step(model_out, latents, next_in, rows, Cdim, cfg, guidance_scale, 
                                            1 if cfg else 0, float(guidance_scale), float(alpha_t), float(alpha_prev),
                                            dtype_code(model_out.dtype), _stream()), "hallo_cfg_ddim_step")
     return latents
+
+
+def frames_to_uint8(x, out=None):
+    """x fp32 [F, C, HW] (planar, values in [0, 1]) -> uint8 [F, HW, C] = np.clip(x * 255, 0, 255).astype(np.uint8)
+    (hallo/utils/util.py:308-312), byte-exact."""
+    _chk_dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    Fr, Cc, HW = x.shape
+    if out is None:
+        out = torch.empty((Fr, HW, Cc), device=x.device, dtype=torch.uint8)
+    _l.check(_l.load().hallo_frames_to_uint8(_p(x), _p(out), Fr, Cc, HW, _stream()), "hallo_frames_to_uint8")
+    return out

@@ -38,6 +38,10 @@ int hallo_abi_version(void);
  * big-tile kernel wherever applicable, 6 auto over all (default); "split_k" = 0 / 1 (auto, default);
  * "v3_min_tiles" = smallest grid the auto rule gives to the big-tile kernel.  Returns -22 for unknown names / values. */
 int hallo_set_option(const char* name, int value);
+/* Read an option back; "last_gemm_kernel" = the kernel the last hallo_gemm / hallo_conv3x3_nhwc call launched, as
+ * 100 * k + 10 * mode + s: k = 1 gemm_kernel / 2 gemm2_kernel / 3 gemm3_kernel, mode = 0 gemm / 1 conv3x3 / 2 geglu,
+ * s = LDS stages (gemm2) or TM (gemm3).  Used by bench.py to report achieved rates per kernel SYMBOL.  -22 = unknown. */
+int hallo_get_option(const char* name);
 
 /* ------------------------------------------------------------------------------------------
  * hallo_gemm: C[M,N] = act( alpha * rowscale[m] * (A[M,K] . W[N,K]^T + bias) + residual )
@@ -211,6 +215,14 @@ int hallo_timestep_embedding(const float* t, void* out, int batch, int dim, int 
 int hallo_cfg_ddim_step(const void* model_out, int64_t ldm, float* latents, void* next_in, int64_t ldn,
                         int rows, int C, int cfg, float guidance_scale, float alpha_t, float alpha_prev,
                         int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * hallo_frames_to_uint8: decoded frames, planar fp32 [frames, channels, hw] in [0, 1], to interleaved uint8
+ * [frames, hw, channels] = np.clip(x * 255, 0, 255).astype(np.uint8) of tensor_to_video
+ * (hallo/utils/util.py:308-312).  Byte-exact with the numpy expression on the same fp32 input; done on the device so
+ * that the D2H copy / the 8-GPU all-gather of a clip moves 4x fewer bytes.
+ */
+int hallo_frames_to_uint8(const float* x, uint8_t* y, int frames, int channels, int64_t hw, void* stream);
 
 #ifdef __cplusplus
 }

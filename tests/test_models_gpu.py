@@ -166,3 +166,78 @@ def test_pipeline_end_to_end(nets, guidance, report):
     report.append({"test": f"pipeline_frames_psnr[gs={guidance}]", "dtype": str(dtype), "psnr_db": p, "tol_psnr_db": 35.0})
     print("PSNR", p)
     assert p >= 35.0
+
+
+# ------------------------------------------------------------------------------------------------
+# SURVEY 8f rows 1 + 3: the sliding-window driver (motion-frame carry on the device, shared generator stream)
+# and the uint8 output conversion
+def test_frames_to_uint8_byte_exact(report):
+    import os
+    import numpy as np
+    from hallo_amd import ops
+    from hallo_amd.animate import video as V
+    from oracle import driver_ref as D
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "driver_golden.npz"))
+    vin = torch.from_numpy(g["video_in"]).cuda()
+    assert np.array_equal(V.frames_to_uint8(vin).cpu().numpy(), g["video_u8"])          # the reference's own bytes
+    gen = torch.Generator().manual_seed(3)
+    v = torch.rand((3, 5, 64, 48), generator=gen) * 1.5 - 0.25
+    v.view(-1)[:512] = torch.arange(512) / 255.0 / 2.0          # exact k/255 and k/510 boundaries
+    got = V.frames_to_uint8(v.cuda()).cpu().numpy()
+    assert np.array_equal(got, D.frames_to_uint8(v))
+    report.append({"test": "frames_to_uint8", "byte_exact": True})
+
+
+def test_sliding_window_driver(nets, report):
+    """Two clips through hallo_amd.animate.video.generate_video vs the oracle driver (oracle/driver_ref.py) around the
+    oracle pipeline: clip 2's motion frames are clip 1's last two decoded frames on both sides."""
+    dtype, o, n = nets
+    from oracle import harness as Hn
+    from oracle import hallo_ref as H
+    from oracle import driver_ref as D
+    from hallo_amd.animate import video as V
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline, FaceAnimatePipelineOutput
+    from hallo_amd.scheduler import DDIMScheduler
+    S, Fr, steps, gs, T = 128, 4, 2, 3.5, 9
+    rd = lambda t: t.to(dtype).float()
+    g = torch.Generator().manual_seed(77)
+    src = rd(torch.rand((3, S, S), generator=g) * 2 - 1)
+    region = torch.zeros((3, S, S))
+    region[:, S // 4: 3 * S // 4, S // 4: 3 * S // 4] = 1.0
+    emb = rd(torch.randn((512,), generator=g))
+    lat = S // 8
+    mk = lambda: [rd(torch.rand((1, (lat // 2 ** l) ** 2), generator=g)) for l in range(4)]
+    fm, cm, lm = mk(), mk(), mk()
+    audio = rd(torch.randn((T, 12, 16), generator=g))
+    ms = [1.0, 0.8, 1.2]
+
+    def oracle_call(**kw):
+        v = H.animate(o["vae"], o["reference_unet"], o["denoising_unet"], o["face_locator"], o["imageproj"],
+                      H.make_scheduler(), kw["ref_image"], kw["face_emb"], kw["audio_tensor"], kw["face_mask"],
+                      kw["pixel_values_full_mask"], kw["pixel_values_face_mask"], kw["pixel_values_lip_mask"], kw["width"],
+                      kw["height"], kw["video_length"], kw["num_inference_steps"], kw["guidance_scale"],
+                      motion_scale=kw["motion_scale"], generator=kw["generator"])
+        return FaceAnimatePipelineOutput(videos=v)
+    with torch.no_grad():
+        vo = D.generate_video(oracle_call, lambda a: rd(o["audioproj"](a)), src, region, emb, fm, cm, lm, audio, Fr, 2, (S, S),
+                              steps, gs, ms, audio_length=7)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched)
+    dev = torch.device("cuda:0")
+    args = (pipe, n["audioproj"], src.to(dev), region.to(dev), emb.to(dev), fm, cm, lm, audio.to(dev, dtype))
+    kw = dict(clip_length=Fr, n_motion_frames=2, img_size=(S, S), inference_steps=steps, cfg_scale=gs, motion_scale=ms,
+              audio_length=7)
+    vn = V.generate_video(*args, output="float", **kw)
+    assert vn.shape == vo.shape == (3, 7, S, S) and vn.dtype == torch.float32 and not vn.is_cuda
+    p1, p2 = Hn.psnr(vn[:, :Fr], vo[:, :Fr]), Hn.psnr(vn[:, Fr:], vo[:, Fr:])
+    report.append({"test": "sliding_window_psnr", "dtype": str(dtype), "psnr_clip1_db": p1, "psnr_clip2_db": p2,
+                   "tol_psnr_db": 35.0})
+    print("driver PSNR", p1, p2)
+    assert p1 >= 35.0 and p2 >= 35.0
+    # uint8 output = the byte conversion of the float output of the same run (same seed -> same latents)
+    u8 = V.generate_video(*args, output="uint8", **kw)
+    assert u8.shape == (7, S, S, 3) and u8.dtype == torch.uint8
+    # (two separate runs: GroupNorm's partial sums are combined with LDS atomics, so the last bit may differ)
+    assert (u8.int() - torch.from_numpy(D.frames_to_uint8(vn)).int()).abs().max().item() <= 1
