@@ -402,7 +402,9 @@ def main():
                            "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "source": tj.get("_source", "profiles/r1_pmc_traffic.json")}
         except Exception:
             pass
-        mfma_bound = name.startswith(("gemm", "attn_kernel"))
+        # bound by arithmetic intensity against the machine balance (2500 TFLOP/s / 8 TB/s = 312 flop/B): the K = 320
+        # projection GEMMs that dominate the step sit BELOW it (~255 flop/B) -- they are HBM-bound kernels
+        mfma_bound = d["flop"] / max(d["bytes"], 1.0) >= PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
         if mfma_bound:
             out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(d["tflops"], 1), "peak": PEAK_BF16_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(d["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,

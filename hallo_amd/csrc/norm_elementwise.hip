@@ -17,19 +17,24 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ ws,
                                                        int HW, int C, int groups, int rows_per_chunk) {
   using V8 = typename Vec<T>::v8;
-  __shared__ float s_sum[GN_MAX_GROUPS], s_sq[GN_MAX_GROUPS];
+  // Deterministic block reduction (no float atomics: results are bit-reproducible run to run).  A thread owns at most
+  // 2 vector columns (C <= 4096) and a vector of 8 channels spans at most 2 groups (channels per group >= 4), so every
+  // thread publishes up to 4 (group, sum, sumsq) runs; 8 threads per group then add the runs in a fixed order.
+  __shared__ float s_rs[4][256], s_rq[4][256];
+  __shared__ int s_rg[4][256];
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, img = blockIdx.y, nchunks = gridDim.x;
   const int vpr = C / 8;
   const int cpg = C / groups;
-  if (tid < GN_MAX_GROUPS) { s_sum[tid] = 0.0f; s_sq[tid] = 0.0f; }
-  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) s_rg[r][tid] = -1;
   const int r_begin = chunk * rows_per_chunk;
   const int r_end = min(HW, r_begin + rows_per_chunk);
   // vector columns are distributed over threads; threads beyond a multiple of vpr take extra rows
   const int tpr = vpr <= 256 ? vpr : 256;          // threads that span one row
   const int row_lanes = 256 / tpr;                 // rows processed concurrently
   const int my_row = tid / tpr, my_v0 = tid % tpr;
+  int nrun = 0;
   if (my_row < row_lanes) {
     for (int v = my_v0; v < vpr; v += tpr) {
       float a[8], q[8];
@@ -55,29 +60,42 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float f = to_f32(val[e]); a[e] += f; q[e] += f * f; }
       }
-      // the 8 channels of a vector are consecutive: runs of equal group index are combined before the LDS atomics
+      // the 8 channels of a vector are consecutive: runs of equal group index are combined before publishing
       int g_run = (v * 8) / cpg;
       float sa = 0.0f, sq = 0.0f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int g = (v * 8 + e) / cpg;
         if (g != g_run) {
-          atomicAdd(&s_sum[g_run], sa);
-          atomicAdd(&s_sq[g_run], sq);
+          if (nrun < 4) { s_rg[nrun][tid] = g_run; s_rs[nrun][tid] = sa; s_rq[nrun][tid] = sq; }
+          ++nrun;
           sa = 0.0f; sq = 0.0f; g_run = g;
         }
         sa += a[e];
         sq += q[e];
       }
-      atomicAdd(&s_sum[g_run], sa);
-      atomicAdd(&s_sq[g_run], sq);
+      if (nrun < 4) { s_rg[nrun][tid] = g_run; s_rs[nrun][tid] = sa; s_rq[nrun][tid] = sq; }
+      ++nrun;
     }
   }
   __syncthreads();
-  if (tid < groups) {
-    float* o = ws + (((long)img * nchunks + chunk) * groups + tid) * 2;
-    o[0] = s_sum[tid];
-    o[1] = s_sq[tid];
+  {
+    const int g = tid >> 3, part = tid & 7;     // 8 threads per group, each scans 32 publishers in index order
+    float s = 0.0f, q = 0.0f;
+    for (int t = part * 32; t < part * 32 + 32; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (s_rg[r][t] == g) { s += s_rs[r][t]; q += s_rq[r][t]; }
+      }
+    }
+    // fixed-shape tree over the 8 parts (lanes 8g .. 8g+7 of one wave)
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (part == 0 && g < groups) {
+      float* o = ws + (((long)img * nchunks + chunk) * groups + g) * 2;
+      o[0] = s;
+      o[1] = q;
+    }
   }
 }
 
@@ -470,6 +488,7 @@ extern "C" int hallo_groupnorm_nhwc(const void* x, void* y, const void* gamma, c
   if (!x || !y || !gamma || !beta || !workspace) return -22;
   if (n_img <= 0 || HW <= 0 || C <= 0 || (C & 7) || groups <= 0 || groups > GN_MAX_GROUPS || C % groups) return -22;
   if (n_img > 65535) return -22;
+  if (C > 4096 || C / groups < 2) return -22;     // the deterministic reduction publishes <= 4 group runs per thread
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == DT_F16) return launch_groupnorm<_Float16>(x, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, st);
   if (dtype == DT_BF16) return launch_groupnorm<__bf16>(x, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, st);
