@@ -131,7 +131,7 @@ class UNet3DConditionModel(HalloModule):
         """unet_3d.py:717-839: SD-1.5 2-D UNet weights + motion-module checkpoint -> 3-D UNet (strict=False)."""
         from ..checkpoint import load_unet3d_pretrained_2d
         return load_unet3d_pretrained_2d(cls, pretrained_model_path, motion_module_path, subfolder,
-                                         unet_additional_kwargs, mm_zero_proj_out)
+                                         unet_additional_kwargs, mm_zero_proj_out, use_landmark)
 
     # ---------------------------------------------------------------- plugin surface
     @property

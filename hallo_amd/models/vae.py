@@ -157,6 +157,18 @@ class AutoencoderKL(HalloModule):
         self.quant_conv = _Conv1x1Small(2 * latent_channels, 2 * latent_channels)
         self.post_quant_conv = _Conv1x1Small(latent_channels, latent_channels)
 
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        cfg = dict(config)
+        cfg.update(kwargs)
+        return cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, subfolder=None, **kw):
+        """diffusers AutoencoderKL.from_pretrained (scripts/inference.py:193-194) for a local sd-vae-ft-mse directory."""
+        from ..checkpoint import load_vae_pretrained
+        return load_vae_pretrained(cls, pretrained_model_path, subfolder)
+
     # -- token-major API used by the pipeline ------------------------------------------------
     def encode_tokens(self, x, n, H, W, scale=1.0):
         """x [n, H*W, 8] (3 image channels zero-padded) -> scale * latent mean, [n, h*w, 8] (4 channels + zeros)."""
