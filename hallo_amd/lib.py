@@ -105,6 +105,8 @@ SYMBOLS = {
                                      C.c_void_p]),
     "hallo_nhwc_to_nchw_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float,
                                          C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "hallo_face_xattn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "hallo_frames_to_uint8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "hallo_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hallo_cfg_ddim_step": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,

@@ -127,11 +127,23 @@ class TemporalBasicTransformerBlock(nn.Module):
             # "b n c -> (b f) n c" (transformer_3d.py:189-192): frame row r uses enc[r // f]
             ex = lambda t: t.unsqueeze(1).expand(b, video_length, T, Cd).reshape(n, T, Cd)
             return ex(kf), ex(vf)
-        kf, vf = cache.get(self, "face_kv", face_kv)
-        nh = self.norm2.run(x)
-        q2 = a2.q(nh.view(n * L, Cd)).view(n, L, Cd)
-        a = ops.attention(q2, kf, vf, a2.heads, q_prescaled=True)
-        x = a2.out(a, residual=x)
+        T = enc.shape[1]
+        if T == 4 and a2.heads <= 8 and Cd % 32 == 0 and (video_length * L) % 32 == 0:
+            # norm2 + to_q + SDPA over the 4 face tokens + to_out + residual as ONE pass over x: with H*T <= 32
+            # (head, token) pairs both projections are per-clip constants (hallo_face_xattn)
+            def face_consts():
+                k0, v0 = a2.kv(enc)                                # [b, T, C]
+                return ops.face_xattn_constants(a2.to_q.weight, k0, v0, a2.to_out[0].weight, self.norm2.weight,
+                                                self.norm2.bias, a2.heads, x.dtype)
+            sg, g, bb, owp = cache.get(self, "face_fused", face_consts)
+            x = ops.face_xattn(x.view(n * L, Cd), sg, g, bb, owp, a2.to_out[0].bias, video_length * L,
+                               self.norm2.eps).view(n, L, Cd)
+        else:
+            kf, vf = cache.get(self, "face_kv", face_kv)
+            nh = self.norm2.run(x)
+            q2 = a2.q(nh.view(n * L, Cd)).view(n, L, Cd)
+            a = ops.attention(q2, kf, vf, a2.heads, q_prescaled=True)
+            x = a2.out(a, residual=x)
         return self.ff.run(self.norm3.run(x), residual=x)
 
 

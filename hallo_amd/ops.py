@@ -327,3 +327,43 @@ def frames_to_uint8(x, out=None):
         out = torch.empty((Fr, HW, Cc), device=x.device, dtype=torch.uint8)
     _l.check(_l.load().hallo_frames_to_uint8(_p(x), _p(out), Fr, Cc, HW, _stream()), "hallo_frames_to_uint8")
     return out
+
+
+def face_xattn(x, sg, g, b, owp, bo, rows_per_batch, eps, out=None):
+    """y = x + to_out(SDPA(to_q(LN(x)), K, V)) over 32 (head, token) pairs with the projections / LayerNorm affine folded
+    into per-clip constants (see include/hallo_amd.h: hallo_face_xattn).  x [rows, C]; out may be x."""
+    _chk_dev(x, sg, owp)
+    rows, Cd = x.shape
+    assert x.is_contiguous() and sg.shape[-2:] == (32, Cd) and owp.shape[-2:] == (Cd, 32)
+    assert g.dtype == torch.float32 and b.dtype == torch.float32 and g.is_contiguous() and b.is_contiguous()
+    assert sg.is_contiguous() and owp.is_contiguous() and sg.dtype == x.dtype and owp.dtype == x.dtype
+    if out is None:
+        out = torch.empty_like(x)
+    _l.check(_l.load().hallo_face_xattn(_p(x), _p(out), _p(sg), _p(g), _p(b), _p(owp), _p(bo), rows, Cd,
+                                         int(rows_per_batch), float(eps), dtype_code(x.dtype), _stream()),
+             "hallo_face_xattn")
+    return out
+
+
+def face_xattn_constants(wq, kf, vf, wo, gamma, beta, heads, dtype):
+    """Per-clip constant folding for face_xattn (fp32 torch math on a handful of [32, C] matrices, once per clip and
+    block).  wq [C, C] (to_q.weight), wo [C, C] (to_out[0].weight), kf / vf [nb, T, C] projected face tokens
+    (heads * T must be 32), gamma / beta [C] of norm2."""
+    nb, T, Cd = kf.shape
+    hd = Cd // heads
+    assert T == 4 and heads <= 8, "the fused kernel covers 8 heads x 4 tokens (fewer heads are zero-padded)"
+    f = lambda t: t.float()
+    HT = heads * T
+    sw = torch.zeros((nb, 32, Cd), device=kf.device, dtype=torch.float32)
+    sw[:, :HT] = torch.einsum("bthd,hdc->bhtc", f(kf).view(nb, T, heads, hd), f(wq).view(heads, hd, Cd)).reshape(nb, HT, Cd)
+    sw = sw * q_scale(hd)
+    sg = (sw * f(gamma)).to(dtype).contiguous()
+    g = sg.float().sum(-1).contiguous()                                   # from the ROUNDED sg: the kernel multiplies x by it
+    b = (sw * f(beta)).sum(-1).contiguous()
+    ow = torch.zeros((nb, 32, Cd), device=kf.device, dtype=torch.float32)  # padded heads: uniform p times zero rows
+    ow[:, :HT] = torch.einsum("bthd,chd->bhtc", f(vf).view(nb, T, heads, hd), f(wo).view(Cd, heads, hd)).reshape(nb, HT, Cd)
+    # k-slot order of the second MFMA: slot (ks2, hi, e) <-> (h,t) = 8*(2*ks2 + (e >> 2)) + 4*hi + (e & 3)
+    ks2, hi, e = torch.meshgrid(torch.arange(2), torch.arange(2), torch.arange(8), indexing="ij")
+    j = (8 * (2 * ks2 + (e >> 2)) + 4 * hi + (e & 3)).reshape(-1).to(ow.device)
+    owp = ow[:, j, :].permute(0, 2, 1).to(dtype).contiguous()            # [nb, C, 32]
+    return sg, g, b, owp

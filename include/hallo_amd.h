@@ -217,6 +217,21 @@ int hallo_cfg_ddim_step(const void* model_out, int64_t ldm, float* latents, void
                         int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * hallo_face_xattn: y = x + to_out(SDPA(to_q(LayerNorm(x)), K_face, V_face)) for a cross-attention over H*T = 32
+ * (head, token) pairs -- norm2 + attn2 + residual of the spatial transformer block
+ * (hallo/models/mutual_self_attention.py:286-303; 4 face tokens x 8 heads) in ONE pass over x.
+ * The per-clip constants fold the projections and the LayerNorm affine (fp32 host math, then rounded once):
+ *   sg  [nb][32][C]  dtype  gamma_c * c0 * sum_d Wq[h*hd+d, c] K[b, t, h*hd+d],  (h,t) = h*T + t, c0 = hd^-0.5 * log2(e)
+ *   g   [nb][32]     fp32   sum_c sg[c]            b [nb][32] fp32   sum_c beta_c * (sg[c] / gamma_c)
+ *   owp [nb][C][32]  dtype  sum_d Wo[c, h*hd+d] V[b, t, h*hd+d] stored as [c][ks2][hi][e] with
+ *                           (h,t) = 8*(2*ks2 + (e >> 2)) + 4*hi + (e & 3)     (the MFMA k-slot order of the kernel)
+ *   bo  [C] dtype           to_out bias
+ * x, y: [rows, C] (y may alias x); batch entry of a row = row / rows_per_batch (a multiple of 32); C % 32 == 0.
+ */
+int hallo_face_xattn(const void* x, void* y, const void* sg, const float* g, const float* b, const void* owp,
+                     const void* bo, int64_t rows, int C, int64_t rows_per_batch, float eps, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * hallo_frames_to_uint8: decoded frames, planar fp32 [frames, channels, hw] in [0, 1], to interleaved uint8
  * [frames, hw, channels] = np.clip(x * 255, 0, 255).astype(np.uint8) of tensor_to_video
  * (hallo/utils/util.py:308-312).  Byte-exact with the numpy expression on the same fp32 input; done on the device so

@@ -369,6 +369,37 @@ def test_attention_prescaled_q(dtype, hd, Lq, Lkv, report):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cd,heads,rows_pb,nb", [(320, 8, 256, 2), (640, 8, 96, 1), (1280, 8, 64, 2), (160, 2, 128, 2)])
+def test_face_xattn_fused(dtype, Cd, heads, rows_pb, nb, report):
+    """hallo_face_xattn vs the unfused chain LayerNorm -> to_q -> SDPA(4 face tokens) -> to_out + residual in fp32
+    (mutual_self_attention.py:286-303).  heads < 8 exercises the zero-padded (head, token) slots; the last case has
+    rows that are not a multiple of 128 per block."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(Cd + heads)
+    rows = rows_pb * nb
+    x = _rand((rows, Cd), dtype, g) + 0.3                     # non-zero row means: the folded LayerNorm must handle them
+    gamma = (1.0 + 0.1 * torch.randn((Cd,), generator=g)).to(dtype).to(_dev())
+    beta = _rand((Cd,), dtype, g, 0.1)
+    wq = _rand((Cd, Cd), dtype, g, Cd ** -0.5)
+    wo = _rand((Cd, Cd), dtype, g, Cd ** -0.5)
+    bo = _rand((Cd,), dtype, g, 0.1)
+    kf = _rand((nb, 4, Cd), dtype, g)
+    vf = _rand((nb, 4, Cd), dtype, g)
+    sg, gg, bb, owp = ops.face_xattn_constants(wq, kf, vf, wo, gamma, beta, heads, dtype)
+    out = ops.face_xattn(x, sg, gg, bb, owp, bo, rows_pb, 1e-5)
+    xf = x.float()
+    nh = torch.nn.functional.layer_norm(xf, (Cd,), gamma.float(), beta.float(), 1e-5)
+    q = (nh @ wq.float().t()).view(nb, rows_pb, Cd)
+    a = ops_ref.sdpa(q, kf, vf, heads).reshape(rows, Cd)
+    ref = a @ wo.float().t() + bo.float() + xf
+    _check(f"face_xattn[{Cd},{heads},{rows_pb}x{nb}]", out, ref, dtype, report)
+    y = x.clone()
+    ops.face_xattn(y, sg, gg, bb, owp, bo, rows_pb, 1e-5, out=y)          # in place
+    assert torch.equal(y, out)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_forced_rescale(dtype, report):
     """One key far above the rest late in the sequence forces the online-softmax rescale path."""
     from hallo_amd import ops
