@@ -464,11 +464,34 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
   const long C3 = 3L * C;
   const int vpp = Wd / 8;                     // 16-byte vectors per part
 
-  for (int u = tid; u < F * 3 * vpp; u += 256) {
-    const int f = u / (3 * vpp), rem = u - f * 3 * vpp;
-    const int part = rem / vpp, v = rem - part * vpp;
-    const long row = ((long)(b * F + f) * HW + pix);
-    st8<T>(&sQKV[f * W3 + part * Wd + v * 8], ld8<T>(qkv + row * C3 + (long)part * C + cbase + v * 8));
+  // all of a thread's 16-byte loads are issued before the first LDS store (one memory latency per workgroup, not one
+  // per loop trip: a `load; store` loop with a runtime trip count waits for every load in turn)
+  {
+    constexpr int MAXU = 8;                     // F * 3 * vpp <= 32 * 3 * 20 = 1920 units -> <= 8 per thread
+    const int total = F * 3 * vpp;
+    V8 tmp[MAXU];
+    int dst[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+      const int u = tid + 256 * i;
+      dst[i] = -1;
+      if (u < total) {
+        const int f = u / (3 * vpp), rem = u - f * 3 * vpp;
+        const int part = rem / vpp, v = rem - part * vpp;
+        const long row = ((long)(b * F + f) * HW + pix);
+        tmp[i] = ld8<T>(qkv + row * C3 + (long)part * C + cbase + v * 8);
+        dst[i] = f * W3 + part * Wd + v * 8;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i)
+      if (dst[i] >= 0) st8<T>(&sQKV[dst[i]], tmp[i]);
+    for (int u = tid + 256 * MAXU; u < total; u += 256) {     // not reached for F <= 32 with <= 160 channels per block
+      const int f = u / (3 * vpp), rem = u - f * 3 * vpp;
+      const int part = rem / vpp, v = rem - part * vpp;
+      const long row = ((long)(b * F + f) * HW + pix);
+      st8<T>(&sQKV[f * W3 + part * Wd + v * 8], ld8<T>(qkv + row * C3 + (long)part * C + cbase + v * 8));
+    }
   }
   __syncthreads();
 

@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         for (int e = 0; e < 8; ++e) { const float f = to_f32(val[e]); a[e] += f; q[e] += f * f; }
       }
       // the 8 channels of a vector are consecutive: runs of equal group index are combined before publishing
+      // (<= 2 runs per vector: channels per group is 4 or >= 6); vector k of this thread owns slots 2k, 2k+1
+      nrun = 2 * ((v - my_v0) / tpr);
       int g_run = (v * 8) / cpg;
       float sa = 0.0f, sq = 0.0f;
 #pragma unroll
@@ -79,23 +81,31 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     }
   }
   __syncthreads();
-  {
-    const int g = tid >> 3, part = tid & 7;     // 8 threads per group, each scans 32 publishers in index order
-    float s = 0.0f, q = 0.0f;
-    for (int t = part * 32; t < part * 32 + 32; ++t) {
+  // stage 1: the row lanes of a vector column hold runs of the same groups -> row lane 0 adds them in lane order
+  if (row_lanes > 1 && my_row == 0) {
+    for (int rl = 1; rl < row_lanes; ++rl) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (s_rg[r][t] == g) { s += s_rs[r][t]; q += s_rq[r][t]; }
+      for (int r = 0; r < 2; ++r) {
+        if (s_rg[r][my_v0] >= 0) { s_rs[r][my_v0] += s_rs[r][rl * tpr + my_v0]; s_rq[r][my_v0] += s_rq[r][rl * tpr + my_v0]; }
       }
     }
-    // fixed-shape tree over the 8 parts (lanes 8g .. 8g+7 of one wave)
+  }
+  __syncthreads();
+  // stage 2: one thread per group walks the vector columns that overlap its channels, in column order
+  if (tid < groups) {
+    const int g = tid;
+    const int v_lo = (g * cpg) >> 3, v_hi = ((g + 1) * cpg - 1) >> 3;
+    float sacc = 0.0f, qacc = 0.0f;
+    for (int v = v_lo; v <= v_hi; ++v) {
+      const int t = v % tpr, base = (v / tpr) * 2;      // column v is held by thread v % tpr, vector slot v / tpr
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-    if (part == 0 && g < groups) {
-      float* o = ws + (((long)img * nchunks + chunk) * groups + g) * 2;
-      o[0] = s;
-      o[1] = q;
+      for (int r = 0; r < 2; ++r) {
+        if (base + r < 4 && s_rg[base + r][t] == g) { sacc += s_rs[base + r][t]; qacc += s_rq[base + r][t]; }
+      }
     }
+    float* o = ws + (((long)img * nchunks + chunk) * groups + g) * 2;
+    o[0] = sacc;
+    o[1] = qacc;
   }
 }
 
@@ -471,7 +481,8 @@ static int launch_groupnorm(const void* x, void* y, const void* gamma, const voi
   const int rpc = (HW + nchunks - 1) / nchunks;
   hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nchunks, n_img), dim3(256), 0, st, reinterpret_cast<const T*>(x), ws,
                      HW, C, groups, rpc);
-  // apply: ~16 KB of data per 256-thread block
+  // apply: ~16 KB of data per 256-thread block (measured: 32-64 KB blocks with 4 loads in flight are 25 % slower --
+  // fewer, longer blocks lose more to the tail than the per-block statistics prologue costs)
   int rows_per_block = (8192 * 2) / (C * 2);
   if (rows_per_block < 1) rows_per_block = 1;
   const int nb = (HW + rows_per_block - 1) / rows_per_block;
@@ -488,7 +499,9 @@ extern "C" int hallo_groupnorm_nhwc(const void* x, void* y, const void* gamma, c
   if (!x || !y || !gamma || !beta || !workspace) return -22;
   if (n_img <= 0 || HW <= 0 || C <= 0 || (C & 7) || groups <= 0 || groups > GN_MAX_GROUPS || C % groups) return -22;
   if (n_img > 65535) return -22;
-  if (C > 4096 || C / groups < 2) return -22;     // the deterministic reduction publishes <= 4 group runs per thread
+  // the deterministic reduction gives a thread 2 vector columns x 2 group runs: C <= 4096 and a vector of 8 channels
+  // may span at most 2 groups (channels per group 4 or >= 6)
+  if (C > 4096 || (C / groups != 4 && C / groups < 6)) return -22;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == DT_F16) return launch_groupnorm<_Float16>(x, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, st);
   if (dtype == DT_BF16) return launch_groupnorm<__bf16>(x, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, st);
