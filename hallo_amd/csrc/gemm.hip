@@ -862,6 +862,8 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
   return -22;
 }
 
+extern "C" int hallo_set_option_norm(const char* name, int value);   // norm_elementwise.hip
+
 extern "C" int hallo_get_option(const char* name) {
   if (!name) return -22;
   if (!strcmp(name, "gemm_variant")) return g_gemm_variant;
@@ -877,5 +879,5 @@ extern "C" int hallo_set_option(const char* name, int value) {
   if (!strcmp(name, "v3_min_tiles")) { if (value < 1) return -22; g_v3_min_tiles = value; return 0; }
   if (!strcmp(name, "conv_fast")) { if (value < 0 || value > 1) return -22; g_conv_fast = value; return 0; }
   if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }
-  return -22;
+  return hallo_set_option_norm(name, value);
 }

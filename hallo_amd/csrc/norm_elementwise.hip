@@ -4,6 +4,7 @@
 // All loads/stores are 16-byte vectors (8 x fp16/bf16); statistics are fp32 (combined in fp64).
 #include "common.h"
 #include "../../include/hallo_amd.h"
+#include <string.h>
 
 namespace hallo {
 
@@ -18,16 +19,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
                                                        int HW, int C, int groups, int rows_per_chunk) {
   using V8 = typename Vec<T>::v8;
   // Deterministic block reduction (no float atomics: results are bit-reproducible run to run).  A thread owns at most
-  // 2 vector columns (C <= 4096) and a vector of 8 channels spans at most 2 groups (channels per group >= 4), so every
-  // thread publishes up to 4 (group, sum, sumsq) runs; 8 threads per group then add the runs in a fixed order.
-  __shared__ float s_rs[4][256], s_rq[4][256];
-  __shared__ int s_rg[4][256];
+  // 2 vector columns (C <= 4096) and a vector of 8 channels spans at most 3 groups (channels per group >= 4), so every
+  // thread publishes up to 2 x 3 (group, sum, sumsq) runs, which are then added in a fixed order.
+  __shared__ float s_rs[6][256], s_rq[6][256];
+  __shared__ int s_rg[6][256];
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, img = blockIdx.y, nchunks = gridDim.x;
   const int vpr = C / 8;
   const int cpg = C / groups;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) s_rg[r][tid] = -1;
+  for (int r = 0; r < 6; ++r) s_rg[r][tid] = -1;
   const int r_begin = chunk * rows_per_chunk;
   const int r_end = min(HW, r_begin + rows_per_chunk);
   // vector columns are distributed over threads; threads beyond a multiple of vpr take extra rows
@@ -61,22 +62,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         for (int e = 0; e < 8; ++e) { const float f = to_f32(val[e]); a[e] += f; q[e] += f * f; }
       }
       // the 8 channels of a vector are consecutive: runs of equal group index are combined before publishing
-      // (<= 2 runs per vector: channels per group is 4 or >= 6); vector k of this thread owns slots 2k, 2k+1
-      nrun = 2 * ((v - my_v0) / tpr);
+      // vector k of this thread owns slots 3k .. (a thread with ONE vector may use all 6: channels per group >= 2;
+      // two vectors per thread only occur for C > 2048, i.e. >= 64 channels per group and <= 2 runs each)
+      nrun = 3 * ((v - my_v0) / tpr);
       int g_run = (v * 8) / cpg;
       float sa = 0.0f, sq = 0.0f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int g = (v * 8 + e) / cpg;
         if (g != g_run) {
-          if (nrun < 4) { s_rg[nrun][tid] = g_run; s_rs[nrun][tid] = sa; s_rq[nrun][tid] = sq; }
+          if (nrun < 6) { s_rg[nrun][tid] = g_run; s_rs[nrun][tid] = sa; s_rq[nrun][tid] = sq; }
           ++nrun;
           sa = 0.0f; sq = 0.0f; g_run = g;
         }
         sa += a[e];
         sq += q[e];
       }
-      if (nrun < 4) { s_rg[nrun][tid] = g_run; s_rs[nrun][tid] = sa; s_rq[nrun][tid] = sq; }
+      if (nrun < 6) { s_rg[nrun][tid] = g_run; s_rs[nrun][tid] = sa; s_rq[nrun][tid] = sq; }
       ++nrun;
     }
   }
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   if (row_lanes > 1 && my_row == 0) {
     for (int rl = 1; rl < row_lanes; ++rl) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
+      for (int r = 0; r < 6; ++r) {
         if (s_rg[r][my_v0] >= 0) { s_rs[r][my_v0] += s_rs[r][rl * tpr + my_v0]; s_rq[r][my_v0] += s_rq[r][rl * tpr + my_v0]; }
       }
     }
@@ -97,10 +99,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     const int v_lo = (g * cpg) >> 3, v_hi = ((g + 1) * cpg - 1) >> 3;
     float sacc = 0.0f, qacc = 0.0f;
     for (int v = v_lo; v <= v_hi; ++v) {
-      const int t = v % tpr, base = (v / tpr) * 2;      // column v is held by thread v % tpr, vector slot v / tpr
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        if (base + r < 4 && s_rg[base + r][t] == g) { sacc += s_rs[base + r][t]; qacc += s_rq[base + r][t]; }
+      const int t = v % tpr;                            // column v is held by thread v % tpr ...
+      const int r_lo = vpr > tpr ? (v / tpr) * 3 : 0, r_hi = vpr > tpr ? r_lo + 3 : 6;   // ... in these slots
+      for (int r = r_lo; r < r_hi; ++r) {
+        if (s_rg[r][t] == g) { sacc += s_rs[r][t]; qacc += s_rq[r][t]; }
       }
     }
     float* o = ws + (((long)img * nchunks + chunk) * groups + g) * 2;
@@ -182,6 +184,135 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm for small feature maps (H*W <= 1024: the 32x32 / 16x16 / 8x8 levels), ONE launch: a workgroup owns a
+// channel slice of whole groups of one image, sums it (pass 1), reduces in a fixed order, then re-reads the slice
+// (L2-resident: <= 160 KB) and writes the normalised values (pass 2).  The two-kernel path above costs ~20 us on these
+// shapes whatever their size (two launches, the fp64 combine in every apply block); slices of one image are placed
+// on one XCD (xcd_remap) so that the 128-byte lines shared by neighbouring slices are fetched once.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                       const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                       int HW, int C, int cpg, int cb, float eps, int silu) {
+  using V8 = typename Vec<T>::v8;
+  __shared__ float s_rs[3][256], s_rq[3][256];
+  __shared__ int s_rg[3][256];
+  __shared__ float s_cs[3][16], s_cq[3][16];      // per (slot, vector column) sums over the row lanes
+  __shared__ float s_mean[16], s_rstd[16];
+  const int tid = threadIdx.x;
+  const int nslices = C / cb;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int img = bid / nslices, slice = bid - img * nslices;
+  const int vps = cb / 8;                           // vector columns of the slice (<= 16)
+  const int lanes = 256 / vps;                      // row lanes
+  const int vi = tid % vps, rl = tid / vps;
+  const bool act = rl < lanes;
+  const int c0 = slice * cb + vi * 8;               // first channel of this thread's vector
+  const int gpb = cb / cpg;                         // groups in the slice
+  const T* xb = x + ((long)img * HW) * C + c0;
+  T* yb = y + ((long)img * HW) * C + c0;
+
+  float a[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = 0.0f; q[e] = 0.0f; }
+  if (act) {
+    int r = rl;
+    for (; r + 3 * lanes < HW; r += 4 * lanes) {
+      const V8 v0 = ld8<T>(xb + (long)r * C), v1 = ld8<T>(xb + (long)(r + lanes) * C);
+      const V8 v2 = ld8<T>(xb + (long)(r + 2 * lanes) * C), v3 = ld8<T>(xb + (long)(r + 3 * lanes) * C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f0 = to_f32(v0[e]), f1 = to_f32(v1[e]), f2 = to_f32(v2[e]), f3 = to_f32(v3[e]);
+        a[e] += (f0 + f1) + (f2 + f3);
+        q[e] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+      }
+    }
+    for (; r < HW; r += lanes) {
+      const V8 v0 = ld8<T>(xb + (long)r * C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float f = to_f32(v0[e]); a[e] += f; q[e] += f * f; }
+    }
+  }
+  // publish <= 3 runs of equal (slice-local) group index per thread (channels per group >= 4)
+  s_rg[0][tid] = -1; s_rg[1][tid] = -1; s_rg[2][tid] = -1;
+  if (act) {
+    int nrun = 0, g_run = (vi * 8) / cpg;
+    float sa = 0.0f, sq = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (vi * 8 + e) / cpg;
+      if (g != g_run) {
+        if (nrun < 3) { s_rg[nrun][tid] = g_run; s_rs[nrun][tid] = sa; s_rq[nrun][tid] = sq; }
+        ++nrun; sa = 0.0f; sq = 0.0f; g_run = g;
+      }
+      sa += a[e];
+      sq += q[e];
+    }
+    if (nrun < 3) { s_rg[nrun][tid] = g_run; s_rs[nrun][tid] = sa; s_rq[nrun][tid] = sq; }
+  }
+  __syncthreads();
+  if (tid < 3 * vps) {                               // (slot, column) reducers: row lanes added in lane order
+    const int slot = tid / vps, col = tid - slot * vps;
+    float sa = 0.0f, sq = 0.0f;
+    if (s_rg[slot][col] >= 0) {
+      for (int l = 0; l < lanes; ++l) { sa += s_rs[slot][l * vps + col]; sq += s_rq[slot][l * vps + col]; }
+    }
+    s_cs[slot][col] = sa;
+    s_cq[slot][col] = sq;
+  }
+  __syncthreads();
+  if (tid < gpb) {                                   // one thread per group: columns in order
+    const int g = tid;
+    const int v_lo = (g * cpg) >> 3, v_hi = ((g + 1) * cpg - 1) >> 3;
+    double sa = 0.0, sq = 0.0;
+    for (int v = v_lo; v <= v_hi; ++v) {
+#pragma unroll
+      for (int slot = 0; slot < 3; ++slot) {
+        if (s_rg[slot][v] == g) { sa += (double)s_cs[slot][v]; sq += (double)s_cq[slot][v]; }
+      }
+    }
+    const double n = (double)HW * cpg;
+    const double mean = sa / n;
+    double var = sq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[g] = (float)mean;
+    s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  if (!act) return;
+  float sc[8], sh[8];
+  {
+    const V8 g8 = ld8<T>(gamma + c0), b8 = ld8<T>(beta + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (vi * 8 + e) / cpg;
+      sc[e] = s_rstd[g] * to_f32(g8[e]);
+      sh[e] = to_f32(b8[e]) - s_mean[g] * sc[e];
+    }
+  }
+  auto apply8 = [&](V8 val) {
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = __builtin_fmaf(to_f32(val[e]), sc[e], sh[e]);
+      if (silu) f = silu_f(f);
+      o[e] = from_f32<T>(f);
+    }
+    return o;
+  };
+  int r = rl;
+  for (; r + 3 * lanes < HW; r += 4 * lanes) {
+    const V8 v0 = ld8<T>(xb + (long)r * C), v1 = ld8<T>(xb + (long)(r + lanes) * C);
+    const V8 v2 = ld8<T>(xb + (long)(r + 2 * lanes) * C), v3 = ld8<T>(xb + (long)(r + 3 * lanes) * C);
+    st8<T>(yb + (long)r * C, apply8(v0));
+    st8<T>(yb + (long)(r + lanes) * C, apply8(v1));
+    st8<T>(yb + (long)(r + 2 * lanes) * C, apply8(v2));
+    st8<T>(yb + (long)(r + 3 * lanes) * C, apply8(v3));
+  }
+  for (; r < HW; r += lanes) st8<T>(yb + (long)r * C, apply8(ld8<T>(xb + (long)r * C)));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -467,6 +598,13 @@ using namespace hallo;
 
 extern "C" int hallo_abi_version(void) { return 2; }
 
+static int g_gn_fused = 1;   // hallo_set_option("gn_fused", 0 | 1): single-launch GroupNorm for small feature maps
+
+extern "C" int hallo_set_option_norm(const char* name, int value) {
+  if (name && !strcmp(name, "gn_fused")) { if (value < 0 || value > 1) return -22; g_gn_fused = value; return 0; }
+  return -22;
+}
+
 extern "C" int hallo_groupnorm_chunks(int HW) {
   int c = (HW + 63) / 64;   // 64 rows per partial-statistics block: >= 1024 blocks at 16 x 64x64 frames
   if (c > 64) c = 64;
@@ -477,6 +615,21 @@ extern "C" int hallo_groupnorm_chunks(int HW) {
 template <typename T>
 static int launch_groupnorm(const void* x, void* y, const void* gamma, const void* beta, float* ws, int n_img,
                             int HW, int C, int groups, float eps, int silu, hipStream_t st) {
+  if (g_gn_fused && HW <= 1024) {
+    // channel slice per workgroup: whole groups, a multiple of 8 channels, 40..128 channels
+    const int cpg = C / groups;
+    int cb = 0;
+    for (int k = 1; cpg >= 4 && k * cpg <= 128; ++k) {
+      if ((k * cpg) % 8 == 0 && groups % k == 0 && k * cpg >= 40) { cb = k * cpg; break; }
+    }
+    if (cb > 0 && (long)(C / cb) * n_img >= 16) {
+      hipLaunchKernelGGL((gn_fused_kernel<T>), dim3((unsigned)((C / cb) * n_img)), dim3(256), 0, st,
+                         reinterpret_cast<const T*>(x), reinterpret_cast<T*>(y), reinterpret_cast<const T*>(gamma),
+                         reinterpret_cast<const T*>(beta), HW, C, cpg, cb, eps, silu);
+      HALLO_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   const int nchunks = hallo_groupnorm_chunks(HW);
   const int rpc = (HW + nchunks - 1) / nchunks;
   hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nchunks, n_img), dim3(256), 0, st, reinterpret_cast<const T*>(x), ws,
@@ -499,9 +652,9 @@ extern "C" int hallo_groupnorm_nhwc(const void* x, void* y, const void* gamma, c
   if (!x || !y || !gamma || !beta || !workspace) return -22;
   if (n_img <= 0 || HW <= 0 || C <= 0 || (C & 7) || groups <= 0 || groups > GN_MAX_GROUPS || C % groups) return -22;
   if (n_img > 65535) return -22;
-  // the deterministic reduction gives a thread 2 vector columns x 2 group runs: C <= 4096 and a vector of 8 channels
-  // may span at most 2 groups (channels per group 4 or >= 6)
-  if (C > 4096 || (C / groups != 4 && C / groups < 6)) return -22;
+  // the deterministic reduction gives a thread 6 (group, sum, sumsq) slots: one vector of 8 channels spanning <= 5
+  // groups (channels per group >= 2), or two vectors (C > 2048) of <= 3 groups each
+  if (C > 4096 || C / groups < 2) return -22;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == DT_F16) return launch_groupnorm<_Float16>(x, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, st);
   if (dtype == DT_BF16) return launch_groupnorm<__bf16>(x, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, st);

@@ -535,6 +535,31 @@ def test_cfg_ddim_step(dtype, cfg, report):
         assert torch.equal(nxt[rows:, :Cd], lat.to(dtype))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,HW,Cd,silu", [(16, 256, 1280, True), (4, 1024, 640, False), (16, 64, 2560, True), (8, 100, 1920, True),
+                                          (4, 256, 128, True), (2, 1024, 960, False)])
+def test_groupnorm_single_launch_path(dtype, n, HW, Cd, silu, report):
+    """Small feature maps take the one-launch kernel (channel slices of whole groups); it must agree with the fp32
+    expression and -- both being deterministic -- be selected purely by shape (gn_fused switch for the A/B)."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(n + HW + Cd)
+    x = _rand((n, HW, Cd), dtype, g) + 0.5
+    gm, bt = _rand((Cd,), dtype, g), _rand((Cd,), dtype, g)
+    out = ops.groupnorm(x, gm, bt, n, HW, 32, 1e-5, silu=silu)
+    ref = ops_ref.groupnorm_nhwc(x, gm, bt, 32, 1e-5, silu=silu)
+    _check(f"groupnorm_fused[{n},{HW},{Cd}]", out, ref, dtype, report)
+    ops.set_option("gn_fused", 0)
+    try:
+        two = ops.groupnorm(x, gm, bt, n, HW, 32, 1e-5, silu=silu)
+    finally:
+        ops.set_option("gn_fused", 1)
+    _check(f"groupnorm_two_kernel[{n},{HW},{Cd}]", two, ref, dtype, report)
+    y = x.clone()
+    ops.groupnorm(y, gm, bt, n, HW, 32, 1e-5, silu=silu, out=y)           # in place
+    assert torch.equal(y, out)
+
+
 def test_operators_are_bit_reproducible():
     """Run-to-run determinism: no float atomics anywhere on the path (GroupNorm statistics are reduced in a fixed
     order), split-K partial sums are combined in a fixed order, the LDS pipelines are race-free."""
