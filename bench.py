@@ -363,7 +363,7 @@ def main():
         "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic (random-init weights of the reference architecture, synthetic clip inputs)",
-        "config": {"workload": f"BASELINE config #2 per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
+        "config": {"workload": f"BASELINE config #{3 if args.guidance > 1.0 else 2} per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
                                f"steps, guidance {args.guidance} ({'CFG, B=2' if args.guidance > 1 else 'no CFG, B=1'}), "
                                "ReferenceNet + VAE encode/decode + D2H inside the timed region",
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (" + RCCL all-gather of frames" if world > 1 else "")},

@@ -675,7 +675,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 }
 
 // gemm_variant: 0 v1 (register-staged 128x128), 1 / 2 v2 (LDS-DMA 128x128) with 1 / 2 LDS stages, 3 auto among v2 only,
-// 4 / 5 force the 256x320 / 128x320 kernel of gemm3.hip wherever it is applicable, 6 auto over everything (default)
+// 4 / 5 force the 256x320 / 128x320 kernel of gemm3.hip wherever it is applicable, 6 auto over everything (default),
+// 7 / 8 force the PERSISTENT 256x320 / 128x320 kernel for GEMM / GEGLU (convs fall back to the auto rule)
 static int g_gemm_variant = 6;
 static int g_split_k = 1;        // 0: never split K, 1: auto
 static int g_conv_fast = 1;      // 0: always use the general (per-thread tap) conv gather
@@ -698,6 +699,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     const float n_eff = (float)a.N / (float)(tn3 * (geglu ? 160 : 320));
     const int t256 = ((a.M + 255) / 256) * tn3 * batch, t128 = ((a.M + 127) / 128) * tn3 * batch;
     int tm = 0, sp = 1;
+    bool persist = false;
     // Split-K factor that brings a grid of `tiles` workgroups to ~one per CU (long K only; fp32 slabs + reduce pass).
     auto split_for = [&](int tiles) {
       if (tiles >= g_v3_min_tiles || geglu || batch != 1 || !g_split_k || !ws || nk < 16) return 1;
@@ -710,6 +712,8 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     if (ok3) {
       if (v == 4) { tm = 2; sp = split_for(t256); }
       else if (v == 5) { tm = 1; sp = split_for(t128); }
+      else if (v == 7 && !conv) { tm = 2; sp = 1; persist = true; }
+      else if (v == 8 && !conv) { tm = 1; sp = 1; persist = true; }
       else if (n_eff > 0.8f) {
         // Auto rule, from tools/kernel_bench.py on MI355X (profiles/r1_kernel_bench_gemm_variants.txt): the big tile pays
         // when the K loop is long enough to amortise its prologue / 6-pass epilogue with one workgroup per CU:
@@ -735,8 +739,8 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
         a.splits = (nk + a.nk_per_split - 1) / a.nk_per_split;
         a.slab = reinterpret_cast<float*>(ws);
       }
-      g_last_kernel = 300 + 10 * (geglu ? 2 : (conv ? 1 : 0)) + tm;
-      launch_gemm3<T>(a, geglu ? 2 : (conv ? 1 : 0), tm, batch, st);
+      g_last_kernel = 300 + 10 * (geglu ? 2 : (conv ? 1 : 0)) + tm + (persist ? 4 : 0);
+      launch_gemm3<T>(a, geglu ? 2 : (conv ? 1 : 0), tm, batch, st, persist);
       HALLO_CHECK_LAUNCH();
       if (a.splits > 1) {
         const long n = (long)a.M * (a.N / 8);
@@ -875,7 +879,7 @@ extern "C" int hallo_get_option(const char* name) {
 
 extern "C" int hallo_set_option(const char* name, int value) {
   if (!name) return -22;
-  if (!strcmp(name, "gemm_variant")) { if (value < 0 || value > 6) return -22; g_gemm_variant = value; return 0; }
+  if (!strcmp(name, "gemm_variant")) { if (value < 0 || value > 8) return -22; g_gemm_variant = value; return 0; }
   if (!strcmp(name, "v3_min_tiles")) { if (value < 1) return -22; g_v3_min_tiles = value; return 0; }
   if (!strcmp(name, "conv_fast")) { if (value < 0 || value > 1) return -22; g_conv_fast = value; return 0; }
   if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }

@@ -37,7 +37,13 @@ constexpr unsigned G3_OOB = 0xFFFFFFFFu;
 #define G3_BLOAD(rs, ldsptr, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ldsptr), 16, (int)(voff), (int)(soff), 0, 0)
 
-template <typename T, int MODE /*0 gemm, 1 conv3x3 (fast gather), 2 geglu*/, int TM>
+// PERSIST: one workgroup per CU walks the tile list (tile = it * gridDim.x + blockIdx.x, XCD-remapped).  The DMA of the
+// NEXT tile's first K step is issued before the epilogue of the current tile -- into slot 1, the epilogue's
+// transposition scratch lives in slot 0 -- so the prologue latency of a tile hides under the previous tile's epilogue
+// and its stores drain under the next tile's MFMAs.  This is what makes the big tile pay on the SHORT-K projections
+// (K = 320 / 640: 5 / 10 K steps per tile), where a one-shot workgroup per CU spends as long in prologue + epilogue
+// as in the K loop and nothing overlaps them.
+template <typename T, int MODE /*0 gemm, 1 conv3x3 (fast gather), 2 geglu*/, int TM, bool PERSIST>
 __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
@@ -48,7 +54,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   constexpr int NP = NA + NW;
   constexpr int PPK = (NP + 3) / 4;      // DMA pieces issued per 16-deep k slice
   constexpr int SLOT = (BM + G3_BN) * G3_BK;
-  __shared__ __attribute__((aligned(16))) T smem[2 * SLOT];
+  // persistent mode keeps slot 1 clear of the 64 KB epilogue scratch at the start of the array
+  constexpr int SLOT_STRIDE = (PERSIST && SLOT < 32768) ? 32768 : SLOT;
+  __shared__ __attribute__((aligned(16))) T smem[SLOT_STRIDE + SLOT];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -56,10 +64,6 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   const int hi = lane >> 5, l31 = lane & 31;
 
   const int nwg = p.tiles_m * p.tiles_n;
-  const int bid = xcd_remap(blockIdx.x, nwg);
-  const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
-  const int m0 = tile_m * BM;
-  const int n0 = GEGLU ? tile_n * 160 : tile_n * G3_BN;
   const long zb = blockIdx.z;
 
   const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + zb * p.sA;
@@ -71,82 +75,83 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   const int lc = lp ^ (((lane >> 4) + 4 * (wave & 1)) & 7);   // logical 16-B chunk this lane fetches (slab parity = wave parity)
   auto clamp32 = [](long bytes) { return (int)(bytes > 0xFFFFFFFFL ? 0xFFFFFFFFL : bytes); };
 
-  const T* Bbase = GEGLU ? B : B + (long)n0 * p.ldb;
-  const long b_rows = GEGLU ? 2L * p.N : (long)(p.N - n0);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(Bbase), 0, clamp32(((b_rows - 1) * p.ldb + p.K) * 2), 0x00020000);
-  unsigned w_voff[NW];
-#pragma unroll
-  for (int j = 0; j < NW; ++j) {
-    const int r = (wave + 8 * j) * 8 + lrow;     // W tile row 0..319
-    long wrow;
-    bool ok;
-    if (GEGLU) {
-      // wave-local row q of 160: [value 0..79 | gate 64..79 | gate 0..63]  (block 2 = value 64..79 + gate 64..79)
-      const int wq = r / 160, q = r - wq * 160;
-      const int t = q >= 80 ? 1 : 0;
-      const int col = q < 80 ? q : (q < 96 ? q - 16 : q - 96);
-      const int cg = n0 + wq * 80 + col;
-      ok = cg < p.N;
-      wrow = (long)t * p.N + cg;
-    } else {
-      ok = n0 + r < p.N;
-      wrow = r;
-    }
-    w_voff[j] = ok ? (unsigned)((wrow * p.ldb + lc * 8) * 2) : G3_OOB;
-  }
-
   const int nk_all = p.K / G3_BK;
   const int kt_begin = (p.splits > 1) ? blockIdx.y * p.nk_per_split : 0;
   const int kt_end = (p.splits > 1) ? min(nk_all, kt_begin + p.nk_per_split) : nk_all;
 
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  unsigned w_voff[NW];
   unsigned a_voff[NA];
   unsigned a_mask[NA];
-  const T* Abase;
-  long a_bytes;
-  if (CONV) {
-    const int hw = p.OH * p.OW;
-    const int img0 = m0 / hw, n_img = p.M / hw;
-    const long img_elems = (long)p.H * p.W * p.Cin;
-    const long shift = ((long)p.pad_t * p.W + p.pad_l) * p.Cin;   // taps are addressed from (-pad_t, -pad_l)
-    Abase = A + img0 * img_elems - shift;
-    a_bytes = ((long)(n_img - img0) * img_elems + shift) * 2;
+  int tap_u = 0, ch_u = 0;     // conv K position: one tap per K tile (Cin % 64 == 0), scalars, for the tile being STAGED
+  // per-tile loader state: descriptors and per-lane byte offsets of this wave's W / A slabs
+  auto setup_loader = [&](int tile_m, int tile_n) {
+    const int m0 = tile_m * BM;
+    const int n0 = GEGLU ? tile_n * 160 : tile_n * G3_BN;
+    const T* Bbase = GEGLU ? B : B + (long)n0 * p.ldb;
+    const long b_rows = GEGLU ? 2L * p.N : (long)(p.N - n0);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Bbase), 0, clamp32(((b_rows - 1) * p.ldb + p.K) * 2), 0x00020000);
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      const int m = m0 + (wave + 8 * j) * 8 + lrow;
-      const int img = m / hw, rem = m - img * hw;
-      const int oy = rem / p.OW, ox = rem - oy * p.OW;
-      const int iy = oy * p.stride - p.pad_t, ix = ox * p.stride - p.pad_l;
-      const unsigned img_off = (unsigned)((img - img0) * img_elems * 2);
-      a_voff[j] = (m < p.M) ? img_off + (unsigned)((((long)oy * p.stride * p.W + ox * p.stride) * p.Cin + lc * 8) * 2) : G3_OOB;
-      unsigned mk = 0;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int vy = iy + t / 3, vx = ix + t % 3;
-        if (m < p.M && vy >= 0 && vy < p.H && vx >= 0 && vx < p.W) mk |= 1u << t;
+    for (int j = 0; j < NW; ++j) {
+      const int r = (wave + 8 * j) * 8 + lrow;     // W tile row 0..319
+      long wrow;
+      bool ok;
+      if (GEGLU) {
+        // wave-local row q of 160: [value 0..79 | gate 64..79 | gate 0..63]  (block 2 = value 64..79 + gate 64..79)
+        const int wq = r / 160, q = r - wq * 160;
+        const int t = q >= 80 ? 1 : 0;
+        const int col = q < 80 ? q : (q < 96 ? q - 16 : q - 96);
+        const int cg = n0 + wq * 80 + col;
+        ok = cg < p.N;
+        wrow = (long)t * p.N + cg;
+      } else {
+        ok = n0 + r < p.N;
+        wrow = r;
       }
-      a_mask[j] = mk;
+      w_voff[j] = ok ? (unsigned)((wrow * p.ldb + lc * 8) * 2) : G3_OOB;
     }
-  } else {
-    Abase = A + (long)m0 * p.lda;
-    const int rows = min(p.M - m0, BM);
-    a_bytes = ((long)(rows - 1) * p.lda + p.K) * 2;
+    const T* Abase;
+    long a_bytes;
+    if (CONV) {
+      const int hw = p.OH * p.OW;
+      const int img0 = m0 / hw, n_img = p.M / hw;
+      const long img_elems = (long)p.H * p.W * p.Cin;
+      const long shift = ((long)p.pad_t * p.W + p.pad_l) * p.Cin;   // taps are addressed from (-pad_t, -pad_l)
+      Abase = A + img0 * img_elems - shift;
+      a_bytes = ((long)(n_img - img0) * img_elems + shift) * 2;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      const int r = (wave + 8 * j) * 8 + lrow;
-      a_voff[j] = (r < rows) ? (unsigned)(((long)r * p.lda + lc * 8) * 2) : G3_OOB;
-      a_mask[j] = 0;
+      for (int j = 0; j < NA; ++j) {
+        const int m = m0 + (wave + 8 * j) * 8 + lrow;
+        const int img = m / hw, rem = m - img * hw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        const int iy = oy * p.stride - p.pad_t, ix = ox * p.stride - p.pad_l;
+        const unsigned img_off = (unsigned)((img - img0) * img_elems * 2);
+        a_voff[j] = (m < p.M) ? img_off + (unsigned)((((long)oy * p.stride * p.W + ox * p.stride) * p.Cin + lc * 8) * 2) : G3_OOB;
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int vy = iy + t / 3, vx = ix + t % 3;
+          if (m < p.M && vy >= 0 && vy < p.H && vx >= 0 && vx < p.W) mk |= 1u << t;
+        }
+        a_mask[j] = mk;
+      }
+      const int k0 = kt_begin * G3_BK;
+      tap_u = k0 / p.Cin;
+      ch_u = k0 - tap_u * p.Cin;
+    } else {
+      Abase = A + (long)m0 * p.lda;
+      const int rows = min(p.M - m0, BM);
+      a_bytes = ((long)(rows - 1) * p.lda + p.K) * 2;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int r = (wave + 8 * j) * 8 + lrow;
+        a_voff[j] = (r < rows) ? (unsigned)(((long)r * p.lda + lc * 8) * 2) : G3_OOB;
+        a_mask[j] = 0;
+      }
     }
-  }
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Abase), 0, clamp32(a_bytes), 0x00020000);
-
-  // conv K position: one tap per K tile (Cin % 64 == 0), tracked in scalars for the tile being STAGED
-  int tap_u = 0, ch_u = 0;
-  if (CONV) {
-    const int k0 = kt_begin * G3_BK;
-    tap_u = k0 / p.Cin;
-    ch_u = k0 - tap_u * p.Cin;
-  }
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Abase), 0, clamp32(a_bytes), 0x00020000);
+  };
+  auto slot_of = [&](int kt) { return PERSIST ? ((kt + 1) & 1) : (kt & 1); };
 
   // DMA piece i of K tile kt into slot `buf`: i < NW -> W slab i, else A slab i - NW
   int soffW = 0, soffA = 0;
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
     }
   };
   auto stage_piece = [&](int i, int buf) {
-    T* dA = smem + buf * SLOT;
+    T* dA = smem + buf * SLOT_STRIDE;
     T* dW = dA + BM * G3_BK;
     if (i < NW) {
       G3_BLOAD(rsB, dW + (wave_u + 8 * i) * 512, w_voff[i], soffW);
@@ -175,6 +180,20 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
     }
   };
 
+  // fragment read offsets: row = base + l31, logical chunk ks*2 + hi -> physical (ks*2) ^ (hi ^ ((l31>>1)&7))
+  const int xsw = hi ^ ((l31 >> 1) & 7);
+  const int fa_row = (wm * 32 * TM + l31) * G3_BK;
+  const int fw_row = (wn * 160 + l31) * G3_BK;
+
+  bool prefetched = false;      // PERSIST: K step 0 of this tile was issued before the previous tile's epilogue
+  for (int it = 0;; ++it) {
+  const int vt = PERSIST ? it * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x;
+  if (vt >= nwg) break;
+  const int bid = xcd_remap(vt, nwg);
+  const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = GEGLU ? tile_n * 160 : tile_n * G3_BN;
+
   f32x16 acc[NW][TM];   // [tn][tm]
 #pragma unroll
   for (int i = 0; i < NW; ++i)
@@ -183,15 +202,13 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // fragment read offsets: row = base + l31, logical chunk ks*2 + hi -> physical (ks*2) ^ (hi ^ ((l31>>1)&7))
-  const int xsw = hi ^ ((l31 >> 1) & 7);
-  const int fa_row = (wm * 32 * TM + l31) * G3_BK;
-  const int fw_row = (wn * 160 + l31) * G3_BK;
-
-  if (kt_begin < kt_end) {
+  // (persistent mode recomputes the loader state here even when K step 0 was prefetched: keeping it live across the
+  // previous tile's epilogue costs ~20 registers next to 160 accumulators and spills)
+  setup_loader(tile_m, tile_n);
+  if (!prefetched && kt_begin < kt_end) {
     stage_begin(kt_begin);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) stage_piece(i, kt_begin & 1);
+    for (int i = 0; i < NP; ++i) stage_piece(i, slot_of(kt_begin));
   }
   // One K step.  MORE (compile-time) = a next tile exists and its DMA is issued from inside this step; the steady-state
   // loop body is branch-free so that the scheduler can run fragment reads of slice ks+1 under the MFMAs of slice ks.
@@ -199,9 +216,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
     constexpr bool MORE = decltype(more_c)::value;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt has landed
     __builtin_amdgcn_s_barrier();                      // ... everyone's has, and everyone is done reading the other slot
-    const int buf = kt & 1;
+    const int buf = slot_of(kt);
     if (MORE) stage_begin(kt + 1);
-    const T* sA = smem + buf * SLOT;
+    const T* sA = smem + buf * SLOT_STRIDE;
     const T* sW = sA + BM * G3_BK;
     // explicit software pipeline over the four 16-deep slices: fragments of slice ks+1 are read while the MFMAs of
     // slice ks run
@@ -250,6 +267,18 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   for (int kt = kt_begin; kt + 1 < kt_end; ++kt) kstep(std::true_type{}, kt);
   if (kt_begin < kt_end) kstep(std::false_type{}, kt_end - 1);
   __builtin_amdgcn_s_barrier();   // every wave is done with the staging LDS: the epilogue reuses it
+  if (PERSIST) {
+    // next tile of this workgroup: loader state + DMA of its K step 0 into slot 1 (the epilogue scratch is in slot 0)
+    const int nvt = vt + (int)gridDim.x;
+    prefetched = nvt < nwg;
+    if (prefetched) {
+      const int nb = xcd_remap(nvt, nwg);
+      setup_loader(nb / p.tiles_n, nb % p.tiles_n);
+      stage_begin(0);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) stage_piece(i, slot_of(0));
+    }
+  }
 
   // ---- epilogue ----
   const T* bias = reinterpret_cast<const T*>(p.bias);
@@ -312,9 +341,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
         __builtin_amdgcn_wave_barrier();
       }
     }
-    return;
-  }
-
+  } else {
   const bool use_res = res && p.res_vec_ok && p.splits <= 1;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
@@ -393,23 +420,53 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
       __builtin_amdgcn_wave_barrier();   // this wave's reads are issued (LDS is in-order per wave) before the next pass's writes
     }
   }
+  }   // !GEGLU
+  if (!PERSIST) break;
+  // The next tile's K step 1 is DMA'd into slot 0 (= this epilogue's scratch) only after the barrier at the top of its
+  // K step 0, which every wave reaches after finishing its epilogue; its scratch READS are retired here.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }   // tile loop
 }
 #undef G3_BLOAD
 
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
 template <typename T>
-void launch_gemm3(const GemmArgs& a, int mode, int tm, int batch, hipStream_t st) {
-  dim3 grid(a.tiles_m * a.tiles_n, a.splits, batch), block(512);
+void launch_gemm3(const GemmArgs& a, int mode, int tm, int batch, hipStream_t st, bool persist) {
+  const int tiles = a.tiles_m * a.tiles_n;
+  dim3 block(512);
+  if (persist && mode != 1) {
+    // one workgroup per CU (147 / 131 KB of LDS each) walking the tile list
+    dim3 grid(tiles < num_cus() ? tiles : num_cus(), 1, batch);
+    if (tm == 2) {
+      if (mode == 2) hipLaunchKernelGGL((gemm3_kernel<T, 2, 2, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((gemm3_kernel<T, 0, 2, true>), grid, block, 0, st, a);
+    } else {
+      if (mode == 2) hipLaunchKernelGGL((gemm3_kernel<T, 2, 1, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((gemm3_kernel<T, 0, 1, true>), grid, block, 0, st, a);
+    }
+    return;
+  }
+  dim3 grid(tiles, a.splits, batch);
   if (tm == 2) {
-    if (mode == 2) hipLaunchKernelGGL((gemm3_kernel<T, 2, 2>), grid, block, 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((gemm3_kernel<T, 1, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((gemm3_kernel<T, 0, 2>), grid, block, 0, st, a);
+    if (mode == 2) hipLaunchKernelGGL((gemm3_kernel<T, 2, 2, false>), grid, block, 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((gemm3_kernel<T, 1, 2, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm3_kernel<T, 0, 2, false>), grid, block, 0, st, a);
   } else {
-    if (mode == 2) hipLaunchKernelGGL((gemm3_kernel<T, 2, 1>), grid, block, 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((gemm3_kernel<T, 1, 1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((gemm3_kernel<T, 0, 1>), grid, block, 0, st, a);
+    if (mode == 2) hipLaunchKernelGGL((gemm3_kernel<T, 2, 1, false>), grid, block, 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((gemm3_kernel<T, 1, 1, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm3_kernel<T, 0, 1, false>), grid, block, 0, st, a);
   }
 }
-template void launch_gemm3<_Float16>(const GemmArgs&, int, int, int, hipStream_t);
-template void launch_gemm3<__bf16>(const GemmArgs&, int, int, int, hipStream_t);
+template void launch_gemm3<_Float16>(const GemmArgs&, int, int, int, hipStream_t, bool);
+template void launch_gemm3<__bf16>(const GemmArgs&, int, int, int, hipStream_t, bool);
 
 }  // namespace hallo
