@@ -35,7 +35,8 @@ int hallo_abi_version(void);
 
 /* Tuning / A-B switch (not part of the numerical contract): "gemm_variant" = 0 register-staged 128x128 kernel,
  * 1 / 2 direct-to-LDS 128x128 kernel with 1 / 2 LDS stages, 3 auto among those, 4 / 5 force the 256x320 / 128x320
- * big-tile kernel wherever applicable, 6 auto over all (default); "split_k" = 0 / 1 (auto, default);
+ * big-tile kernel wherever applicable, 6 auto over all (default), 7 / 8 force the persistent big-tile mode for GEMM / GEGLU;
+ * "split_k" = 0 / 1 (auto, default); "gn_fused" = 0 / 1 (single-launch GroupNorm for small feature maps, default 1);
  * "v3_min_tiles" = smallest grid the auto rule gives to the big-tile kernel.  Returns -22 for unknown names / values. */
 int hallo_set_option(const char* name, int value);
 /* Read an option back; "last_gemm_kernel" = the kernel the last hallo_gemm / hallo_conv3x3_nhwc call launched, as

@@ -54,7 +54,7 @@ def test_argument_validation_returns_einval(lib):
     assert lib.hallo_temporal_attention(None, None, 1, 18, 64, 320, 8, 0.1, 1, None) == -22
     assert lib.hallo_groupnorm_chunks(4096) == 64 and lib.hallo_groupnorm_chunks(4) == 1
     assert lib.hallo_set_option(b"no_such_option", 1) == -22 and lib.hallo_set_option(b"gemm_variant", 2) == 0
-    assert lib.hallo_set_option(b"gemm_variant", 7) == -22 and lib.hallo_set_option(b"gemm_variant", 6) == 0   # back to auto
+    assert lib.hallo_set_option(b"gemm_variant", 9) == -22 and lib.hallo_set_option(b"gemm_variant", 6) == 0   # back to auto
     assert lib.hallo_groupnorm_chunks(64 * 64 * 64) == 64
 
 
