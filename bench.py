@@ -315,7 +315,8 @@ def main():
     pipe, audioproj = build_pipeline(dev, dtype)
     S, Fr = args.size, args.frames
     from hallo_amd.animate.clip_parallel import gather_wave
-    host = torch.empty((Fr, 3, S * S), dtype=torch.float32).pin_memory()
+    # rank 0 receives the whole wave (one clip per rank) and copies ALL of it to the host
+    host = torch.empty((world if rank == 0 else 1, Fr, 3, S * S), dtype=torch.float32).pin_memory()
 
     def one_clip(idx):
         d = clip_inputs(S, Fr, seed=1234 + rank * 1000 + idx, device=dev)
@@ -332,9 +333,9 @@ def main():
         if world > 1:
             g = gather_wave(frames)                            # RCCL all-gather of decoded frames, clip order = rank
             if rank == 0:
-                host.copy_(g[0], non_blocking=True)
+                host.copy_(g, non_blocking=True)
         else:
-            host.copy_(frames, non_blocking=True)
+            host[0].copy_(frames, non_blocking=True)
         return frames
 
     inputs = [one_clip(i) for i in range(args.warmup + args.steps)]
