@@ -22,6 +22,7 @@
 #include "common.h"
 #include "../../include/hallo_amd.h"
 #include <type_traits>
+#include <string.h>
 
 namespace hallo {
 
@@ -538,6 +539,117 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// Temporal attention on the matrix pipe: one WAVE per (batch entry, pixel, head), no LDS, no barrier.
+// The F' <= 32 frames of a pixel are one 32-row MFMA tile:
+//   S^T[j, i] = K[j, :] . Q[i, :]^T   -- K / Q fragments are 16-byte loads straight from the fused [q | k | v] rows
+//                                        (lane = frame, the row stride is the frame stride H*W*3C),
+//   softmax over j is lane-local (+ one lane^32 exchange), P stays in registers,
+//   O^T[d, i] = V^T[d, :] . P^T[:, i] -- V^T fragments are gathered with 2-byte loads (lane = channel d: 64 contiguous
+//                                        bytes per frame row and instruction) in the k-slot order that matches the
+//                                        accumulator layout of S^T, so no transposition pass exists anywhere.
+// The VALU kernel above spends ~18x the tile's bytes in LDS reads (every (i, j) dot re-reads both rows); this one
+// touches each operand once.  A workgroup = 4 consecutive heads of one pixel (320 contiguous bytes per frame row at
+// head dim 40).
+// -------------------------------------------------------------------------------------------
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                                 int F, int HW, int C, int heads, float scale_log2e) {
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  constexpr int HDP = ((HD + 15) / 16) * 16;
+  constexpr int NKS = HDP / 16;
+  constexpr int NDB = (HD + 31) / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int hgroups = heads >> 2;
+  const long item = blockIdx.x;                       // (b, pixel, head group)
+  const int hg = (int)(item % hgroups);
+  const long bp = item / hgroups;                     // b * HW + pixel
+  const int pix = (int)(bp % HW);
+  const long b = bp / HW;
+  const int h = hg * 4 + wave;
+  const long C3 = 3L * C;
+  const long fstride = (long)HW * C3;                 // elements between consecutive frames of one pixel
+  const T* base = qkv + ((b * F) * (long)HW + pix) * C3 + (long)h * HD;
+  const int fr = min(l31, F - 1);                     // rows >= F re-read the last frame (valid memory), masked below
+
+  // ---- S^T = K . Q^T ----
+  const T* qrow = base + fr * fstride;
+  const T* krow = qrow + C;
+  V8 qf[NKS], kf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int d = ks * 16 + hi * 8;
+    qf[ks] = (d < HD) ? ld8<T>(qrow + d) : zero8<T>();
+    kf[ks] = (d < HD) ? ld8<T>(krow + d) : zero8<T>();
+  }
+  // V^T gathers issued early: slot (ks2, hi, e) <-> frame j = 8*(2*ks2 + (e >> 2)) + 4*hi + (e & 3)
+  typedef __attribute__((ext_vector_type(2))) T V2t;
+  V8 vf[NDB][2];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) {
+    const int d = db * 32 + l31;
+    const T* vcol = base + 2 * C + min(d, HD - 1);
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = 8 * (2 * ks2 + (e >> 2)) + 4 * hi + (e & 3);
+        vf[db][ks2][e] = vcol[min(j, F - 1) * fstride];
+      }
+  }
+  f32x16 s;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) s = Vec<T>::mfma32(kf[ks], qf[ks], s);
+
+  // ---- softmax over the key frames j (register r = 4g + jj <-> j = 8g + 4hi + jj; the partner lane holds the rest) ----
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = 8 * (r >> 2) + 4 * hi + (r & 3);
+    s[r] = (j < F) ? s[r] : -3.0e38f;
+    mx = fmaxf(mx, s[r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float mneg = -mx * scale_log2e;
+  float l = 0.0f;
+  V8 pf[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2e, mneg));
+    l += pv;
+    pf[r >> 3][r & 7] = from_f32<T>(pv);
+  }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+
+  // ---- O^T = V^T . P^T, normalise, store rows i < F (lane = query frame, 8-byte stores) ----
+  const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  T* orow = out + ((b * F + fr) * (long)HW + pix) * C + (long)h * HD;
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) {
+    f32x16 o = Vec<T>::mfma32(vf[db][0], pf[0], zero16);
+    o = Vec<T>::mfma32(vf[db][1], pf[1], o);
+    if (l31 < F) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + 8 * g + 4 * hi;
+        if (d0 < HD) {
+          V4 w;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) w[jj] = from_f32<T>(o[4 * g + jj] * inv);
+          *reinterpret_cast<V4*>(orow + d0) = w;
+        }
+      }
+    }
+  }
+}
+
+static int g_temporal_mfma = 1;   // hallo_set_option("temporal_mfma", 0 | 1)
+
 }  // namespace hallo
 
 using namespace hallo;
@@ -568,11 +680,28 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
   return -22;
 }
 
+extern "C" int hallo_set_option_attn(const char* name, int value) {
+  if (name && !strcmp(name, "temporal_mfma")) { if (value < 0 || value > 1) return -22; g_temporal_mfma = value; return 0; }
+  return -22;
+}
+
 extern "C" int hallo_temporal_attention(const void* qkv, void* out, int B, int F, int HW, int C, int heads,
                                         float scale, int dtype, void* stream) {
   if (!qkv || !out || B <= 0 || F <= 0 || F > 32 || HW <= 0 || C <= 0 || heads <= 0) return -22;
   if (C % heads || (C / heads) % 8) return -22;
   const int hd = C / heads;
+  hipStream_t st0 = reinterpret_cast<hipStream_t>(stream);
+  if (g_temporal_mfma && (heads & 3) == 0 && (hd == 40 || hd == 80 || hd == 160) && (dtype == DT_F16 || dtype == DT_BF16)) {
+    const float sl0 = scale * 1.4426950408889634f;
+    dim3 grid((unsigned)((long)B * HW * (heads / 4))), block(256);
+#define HALLO_TMFMA(TT, HDv) hipLaunchKernelGGL((temporal_attn_mfma_kernel<TT, HDv>), grid, block, 0, st0, \
+    reinterpret_cast<const TT*>(qkv), reinterpret_cast<TT*>(out), F, HW, C, heads, sl0)
+    if (dtype == DT_F16) { if (hd == 40) HALLO_TMFMA(_Float16, 40); else if (hd == 80) HALLO_TMFMA(_Float16, 80); else HALLO_TMFMA(_Float16, 160); }
+    else { if (hd == 40) HALLO_TMFMA(__bf16, 40); else if (hd == 80) HALLO_TMFMA(__bf16, 80); else HALLO_TMFMA(__bf16, 160); }
+#undef HALLO_TMFMA
+    HALLO_CHECK_LAUNCH();
+    return 0;
+  }
   // heads per block: largest divisor of `heads` whose slab fits ~40 KB (>= 4 workgroups per CU)
   int hpb = heads;
   auto lds_for = [&](int g) { return (size_t)F * (3 * g * hd + 8) * 2 + (size_t)g * F * (F + 1) * sizeof(float); };

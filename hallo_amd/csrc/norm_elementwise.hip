@@ -600,9 +600,11 @@ extern "C" int hallo_abi_version(void) { return 2; }
 
 static int g_gn_fused = 1;   // hallo_set_option("gn_fused", 0 | 1): single-launch GroupNorm for small feature maps
 
+extern "C" int hallo_set_option_attn(const char* name, int value);   // attention.hip
+
 extern "C" int hallo_set_option_norm(const char* name, int value) {
   if (name && !strcmp(name, "gn_fused")) { if (value < 0 || value > 1) return -22; g_gn_fused = value; return 0; }
-  return -22;
+  return hallo_set_option_attn(name, value);
 }
 
 extern "C" int hallo_groupnorm_chunks(int HW) {
