@@ -122,13 +122,16 @@ class OpProfiler:
         def c_small(a, k, r):
             return 0.0, 0.0
 
+        def c_rs(a, k, r):
+            return 3.0 * a[0].numel(), es * a[0].numel()            # one read pass
+
         def c_fx(a, k, r):
             rows, Cd = a[0].shape          # LN + 32-pair cross-attention + out projection: 2 x (2 * rows * C * 32) flop
             return 4.0 * rows * Cd * 32, es * 2 * rows * Cd
 
         table = dict(gemm=c_gemm, gemm_batched=c_gemmb, conv3x3=c_conv, attention=c_attn, temporal_attention=c_tattn,
                      groupnorm=c_gn, layernorm=c_ln, copy2d=c_copy, softmax_rows=c_sm, nchw_to_nhwc=c_small,
-                     nhwc_to_nchw_f32=c_small, timestep_embedding=c_small, cfg_ddim_step=c_small, face_xattn=c_fx)
+                     nhwc_to_nchw_f32=c_small, timestep_embedding=c_small, cfg_ddim_step=c_small, face_xattn=c_fx, row_stats=c_rs)
         for name, cost in table.items():
             self._orig[name] = getattr(ops, name)
             setattr(ops, name, self._wrap(name, self._orig[name], cost))

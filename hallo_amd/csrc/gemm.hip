@@ -246,7 +246,16 @@ __device__ uint4 g_zero_page[2];
 
 constexpr int TILE_ELEMS = 128 * 64;
 
-template <typename T, int MODE /*0 gemm, 1 conv3x3, 2 geglu*/, int STAGES>
+// LNF: LayerNorm fused into the GEMM (see GemmArgs::ln_colsum).  The A fragments that feed the MFMAs are also
+// reduced to per-row sum / sum of squares with packed dot2 instructions (16 VALU ops per 16-deep slice and lane, in the
+// shadow of 4 MFMAs), so nn.LayerNorm costs no pass over HBM at all; the epilogue applies
+// rstd * (acc - mean * colsum[n]) + bias.  A lane owns output row l31 of each 32-row block in the swapped MFMA
+// form, which is the row its A fragments belong to: the statistics are lane-local up to one lane^32 exchange.
+// LNF = 1 computes the row statistics in the K loop as described; LNF = 2 reads them from GemmArgs::ln_stats
+// (hallo_row_stats: one read pass over A) -- cheaper whenever several N tiles share a row block, because every tile
+// would otherwise redo the statistics of the same rows (measured: the in-loop form makes the N = 2560 GEGLU GEMMs
+// 25 % slower, more than the LayerNorm launch it replaces).
+template <typename T, int MODE /*0 gemm, 1 conv3x3, 2 geglu*/, int STAGES, int LNF>
 __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 ? 3 : 4)) void gemm2_kernel(const GemmArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
@@ -435,6 +444,17 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 ? 3 : 4)) void ge
   const int fa_row = (wm * 64 + l31) * BK;
   const int fb_row = (wn * 64 + l31) * BK;
 
+  float ln_s[2] = {0.0f, 0.0f}, ln_q[2] = {0.0f, 0.0f};      // LNF: partial sum / sum of squares of rows l31, l31 + 32
+  auto row_stats = [&](V8 a, float& sm, float& sq) {
+    typedef __attribute__((ext_vector_type(2))) T V2t;
+    const V2t one2 = {from_f32<T>(1.0f), from_f32<T>(1.0f)};
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const V2t x2 = {a[e], a[e + 1]};
+      sm = dot2(x2, one2, sm);
+      sq = dot2(x2, x2, sq);
+    }
+  };
   auto compute = [&](int buf) {
     const T* sA = smem + buf * 2 * TILE_ELEMS;
     const T* sB = sA + TILE_ELEMS;
@@ -445,6 +465,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 ? 3 : 4)) void ge
       V8 a1 = ld8<T>(sA + fa_row + 32 * BK + co);
       V8 w0 = ld8<T>(sB + fb_row + co);
       V8 w1 = ld8<T>(sB + fb_row + 32 * BK + co);
+      if (LNF == 1) { row_stats(a0, ln_s[0], ln_q[0]); row_stats(a1, ln_s[1], ln_q[1]); }
       acc[0][0] = Vec<T>::mfma32(w0, a0, acc[0][0]);
       acc[0][1] = Vec<T>::mfma32(w0, a1, acc[0][1]);
       acc[1][0] = Vec<T>::mfma32(w1, a0, acc[1][0]);
@@ -518,7 +539,44 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 ? 3 : 4)) void ge
       if (n < p.N) ld8f(bias + n, p.bias_vec_ok, bcol);
     }
   }
-  const bool use_res = !GEGLU && res && p.res_vec_ok && p.splits <= 1;
+  // (the LayerNorm-fused projections have no residual on the path: no prefetch registers for it in that variant)
+  const bool use_res = !GEGLU && !LNF && res && p.res_vec_ok && p.splits <= 1;
+  // LNF: row statistics of rows l31 (tm = 0) and l31 + 32 (tm = 1) of this wave's 64-row block, and the fp32 column
+  // sums of this lane's output columns
+  float ln_mean[2] = {0.0f, 0.0f}, ln_rstd[2] = {1.0f, 1.0f};
+  if (LNF == 1) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float sm = ln_s[t] + __shfl_xor(ln_s[t], 32, 64);      // the partner lane holds the other k chunks of the row
+      const float sq = ln_q[t] + __shfl_xor(ln_q[t], 32, 64);
+      const float mean = sm / (float)p.K;
+      ln_mean[t] = mean;
+      ln_rstd[t] = rsqrtf(fmaxf(sq / (float)p.K - mean * mean, 0.0f) + p.ln_eps);
+    }
+  }
+  // column sums of this lane's output columns: loaded where they are used (L2-resident; keeping 8 more values live
+  // through the epilogue pushes the kernel over 128 VGPRs = 4 workgroups per CU)
+  auto load_gcol = [&](float* gc) {
+    if (GEGLU) {
+      const int n = n0 + wn * 32 + rc * 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gc[j] = 0.0f;
+      if (n < p.N) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_colsum + n), b = *reinterpret_cast<const f32x4*>(p.ln_colsum + p.N + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gc[j] = a[j]; gc[4 + j] = b[j]; }
+      }
+    } else {
+      const int n = n0 + wn * 64 + rc * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gc[j] = 0.0f;
+      if (n < p.N) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_colsum + n), b = *reinterpret_cast<const f32x4*>(p.ln_colsum + n + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gc[j] = a[j]; gc[4 + j] = b[j]; }
+      }
+    }
+  };
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
     // residual rows of this half (4 row groups x 8 columns per lane): issued before the LDS transposition so
@@ -548,10 +606,29 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 ? 3 : 4)) void ge
     for (int i = 0; i < 4; ++i) {
       const int rr = rr0 + 8 * i;
       const int m = m0 + wm * 64 + tm * 32 + rr;
+      // LNF: statistics of row rr live in lane rr (either half)
+      float r_mean = 0.0f, r_rstd = 1.0f;
+      if (LNF == 1) {
+        r_mean = __shfl(ln_mean[tm], rr, 64);
+        r_rstd = __shfl(ln_rstd[tm], rr, 64);
+      } else if (LNF == 2) {
+        const float2 st2 = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)min(m, p.M - 1));
+        r_mean = st2.x;
+        r_rstd = st2.y;
+      }
+      float gcol[8];
+      if (LNF) load_gcol(gcol);
       if (GEGLU) {
         const int n = n0 + wn * 32 + rc * 4;
-        const f32x4 hv = *reinterpret_cast<const f32x4*>(tile + rr * 64 + ((rc ^ (rr & 15)) * 4));
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(tile + rr * 64 + (((8 + rc) ^ (rr & 15)) * 4));
+        f32x4 hv = *reinterpret_cast<const f32x4*>(tile + rr * 64 + ((rc ^ (rr & 15)) * 4));
+        f32x4 gv = *reinterpret_cast<const f32x4*>(tile + rr * 64 + (((8 + rc) ^ (rr & 15)) * 4));
+        if (LNF) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            hv[j] = r_rstd * (hv[j] - r_mean * gcol[j]);
+            gv[j] = r_rstd * (gv[j] - r_mean * gcol[4 + j]);
+          }
+        }
         if (m < p.M && n < p.N) {
           V4 w;
 #pragma unroll
@@ -571,6 +648,10 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 ? 3 : 4)) void ge
         } else if (m < p.M && n < p.N) {
           float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
           float t8[8];
+          if (LNF) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = r_rstd * (o[j] - r_mean * gcol[j]);
+          }
           const float br = (bias && p.bias_per_row) ? to_f32(bias[m]) : 0.0f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] += bcol[j] + br;
@@ -691,9 +772,14 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
   const int nk = (a.K + BK - 1) / BK;
   a.splits = 1; a.nk_per_split = 0; a.slab = nullptr;
   int v = a.vec_ok ? g_gemm_variant : 0;
+  const bool lnf = a.ln_colsum != nullptr;      // fused LayerNorm: 128x128 LDS-DMA kernel only, no split-K
+  if (lnf) {
+    if (!a.vec_ok || conv) return -22;
+    v = (v == 1 || v == 2) ? v : 3;
+  }
 
   // ---- big-tile kernel (gemm3.hip): 256x320 or 128x320 output tiles, one workgroup per CU ----
-  if (v >= 4) {
+  if (v >= 4 && !lnf) {
     const bool ok3 = (a.K % 64 == 0) && (!conv || a.conv_fast) && a.N >= 160;
     const int tn3 = geglu ? (a.N + 159) / 160 : (a.N + 319) / 320;
     const float n_eff = (float)a.N / (float)(tn3 * (geglu ? 160 : 320));
@@ -756,7 +842,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
   // auto: one LDS stage (4 workgroups per CU hide each other's load latency) when the grid fills the chip several
   // times over, two stages (in-workgroup prefetch) for small grids
   if (v == 3) v = (tiles * batch >= 640) ? 1 : 2;
-  if (v != 0 && !geglu && batch == 1 && g_split_k && ws && tiles < 384 && nk >= 32) {
+  if (v != 0 && !geglu && !lnf && batch == 1 && g_split_k && ws && tiles < 384 && nk >= 32) {
     // small grids with a long K loop (8x8 / 16x16 feature maps, K up to 23040): split K so that >= ~768 workgroups
     // are in flight; partial sums go to an fp32 slab and a second pass applies the epilogue in a fixed order
     int sp = (768 + tiles - 1) / tiles;
@@ -776,13 +862,21 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     else if (conv) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, 0, st, a);
   } else if (v == 1) {
-    if (geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 1>), grid, block, 0, st, a);
-    else if (conv) hipLaunchKernelGGL((gemm2_kernel<T, 1, 1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((gemm2_kernel<T, 0, 1>), grid, block, 0, st, a);
+    if (lnf && a.ln_stats && geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 1, 2>), grid, block, 0, st, a);
+    else if (lnf && a.ln_stats) hipLaunchKernelGGL((gemm2_kernel<T, 0, 1, 2>), grid, block, 0, st, a);
+    else if (lnf && geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 1, 1>), grid, block, 0, st, a);
+    else if (lnf) hipLaunchKernelGGL((gemm2_kernel<T, 0, 1, 1>), grid, block, 0, st, a);
+    else if (geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 1, 0>), grid, block, 0, st, a);
+    else if (conv) hipLaunchKernelGGL((gemm2_kernel<T, 1, 1, 0>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm2_kernel<T, 0, 1, 0>), grid, block, 0, st, a);
   } else {
-    if (geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 2>), grid, block, 0, st, a);
-    else if (conv) hipLaunchKernelGGL((gemm2_kernel<T, 1, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((gemm2_kernel<T, 0, 2>), grid, block, 0, st, a);
+    if (lnf && a.ln_stats && geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 2, 2>), grid, block, 0, st, a);
+    else if (lnf && a.ln_stats) hipLaunchKernelGGL((gemm2_kernel<T, 0, 2, 2>), grid, block, 0, st, a);
+    else if (lnf && geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 2, 1>), grid, block, 0, st, a);
+    else if (lnf) hipLaunchKernelGGL((gemm2_kernel<T, 0, 2, 1>), grid, block, 0, st, a);
+    else if (geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 2, 0>), grid, block, 0, st, a);
+    else if (conv) hipLaunchKernelGGL((gemm2_kernel<T, 1, 2, 0>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm2_kernel<T, 0, 2, 0>), grid, block, 0, st, a);
   }
   HALLO_CHECK_LAUNCH();
   if (a.splits > 1) {
@@ -826,6 +920,8 @@ extern "C" int hallo_gemm(const hallo_gemm_desc* d, void* stream) {
   a.alpha = d->alpha; a.act = d->act; a.out_f32 = d->out_f32;
   a.lead_cols = d->lead_cols > 0 ? d->lead_cols : 0; a.lead_alpha = d->lead_cols > 0 ? d->lead_alpha : 1.0f;
   if (a.lead_cols & 7) return -22;
+  a.ln_colsum = d->ln_colsum; a.ln_eps = d->ln_eps; a.ln_stats = d->ln_colsum ? d->ln_stats : nullptr;
+  if (a.ln_colsum && (d->batch != 1 || d->out_f32 || d->bias_per_row)) return -22;
   a.tiles_m = (d->M + BM - 1) / BM;
   a.tiles_n = d->geglu ? (d->N + 63) / 64 : (d->N + BN - 1) / BN;
   a.H = a.W = a.Cin = a.OH = a.OW = a.stride = a.pad_t = a.pad_l = a.upsample = 0;
@@ -854,6 +950,7 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
   a.residual = d->residual; a.ldr = d->ldr > 0 ? d->ldr : d->Cout; a.sR = 0;
   a.alpha = d->alpha; a.act = d->act; a.out_f32 = 0;
   a.lead_cols = 0; a.lead_alpha = 1.0f;
+  a.ln_colsum = nullptr; a.ln_eps = 0.0f; a.ln_stats = nullptr;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW;

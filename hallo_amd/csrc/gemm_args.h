@@ -20,6 +20,10 @@ struct GemmArgs {
   float alpha;
   int lead_cols;            // output columns n < lead_cols get an extra factor lead_alpha (the q part of a fused q|k|v
   float lead_alpha;         // projection carries softmax scale * log2(e) so that the attention kernel can exp2 raw scores)
+  const float* ln_colsum;   // fused LayerNorm (gemm2 only): A is the UN-normalised input, W = gamma * W, bias includes beta . W^T;
+  const float* ln_stats;    // optional [M][2] fp32 (mean, rstd) from hallo_row_stats: then the K loop does no statistics work
+  float ln_eps;             // the kernel accumulates per-row sum / sum of squares over K next to the MFMAs and applies
+                            // out = rstd_m * (acc - mean_m * ln_colsum[n]) + bias.  ln_colsum[n] = sum_k W[n,k] (fp32, [N] / GEGLU [2N])
   int act;
   int out_f32;
   int tiles_n, tiles_m;

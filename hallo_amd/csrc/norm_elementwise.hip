@@ -441,6 +441,49 @@ __global__ __launch_bounds__(256) void layernorm_sub_kernel(const T* __restrict_
   }
 }
 
+// Row statistics only (mean, rstd) -- LayerNorm whose affine is folded into the consuming GEMM (hallo_gemm ln_colsum /
+// ln_stats): LPR lanes share a row, VPL 16-byte vectors per lane, two-pass statistics in registers, one 8-byte store.
+template <typename T, int LPR, int VPL>
+__global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x, float2* __restrict__ st, long rows, int C,
+                                                        float eps) {
+  using V8 = typename Vec<T>::v8;
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & (LPR - 1);
+  const long row = ((long)blockIdx.x * 4 + wave) * RPW + lane / LPR;
+  const bool live = row < rows;
+  const T* xr = x + (live ? row : 0) * C;
+  const int vpr = C / 8;
+  float v[VPL][8];
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vi = sub + LPR * i;
+    if (vi < vpr) {
+      const V8 t = ld8<T>(xr + vi * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = to_f32(t[e]); sum += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.0f;
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)C;
+  float sq = 0.0f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    if (sub + LPR * i < vpr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  if (live && sub == 0) st[row] = make_float2(mean, rsqrtf(sq / (float)C + eps));
+}
+
 // ------------------------------------------------------------------------------------------
 // Row softmax (fp32 in, T out): one workgroup per row.
 // ------------------------------------------------------------------------------------------
@@ -704,6 +747,29 @@ extern "C" int hallo_frames_to_uint8(const float* x, uint8_t* y, int frames, int
   if (!x || !y || frames <= 0 || channels <= 0 || channels > 4 || hw <= 0) return -22;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(frames_to_uint8_kernel, dim3((unsigned)((hw + 255) / 256), frames), dim3(256), 0, st, x, y, channels, (long)hw);
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int hallo_row_stats(const void* x, float* stats, int64_t rows, int C, float eps, int dtype, void* stream) {
+  if (!x || !stats || rows <= 0 || C <= 0 || (C & 7) || C > 1536) return -22;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int vpr = C / 8;
+  float2* o = reinterpret_cast<float2*>(stats);
+#define HALLO_RS(TT, LPRv, VPLv) hipLaunchKernelGGL((row_stats_kernel<TT, LPRv, VPLv>), dim3((unsigned)((rows + 4 * (64 / LPRv) - 1) / (4 * (64 / LPRv)))), \
+    dim3(256), 0, st, reinterpret_cast<const TT*>(x), o, (long)rows, C, eps)
+#define HALLO_RS_T(TT)                                                   \
+  do {                                                                   \
+    if (vpr <= 40) HALLO_RS(TT, 8, 5);          /* C <= 320 */           \
+    else if (vpr <= 80) HALLO_RS(TT, 16, 5);    /* C <= 640 */           \
+    else if (vpr <= 160) HALLO_RS(TT, 32, 5);   /* C <= 1280 */          \
+    else HALLO_RS(TT, 64, 3);                   /* C <= 1536 */          \
+  } while (0)
+  if (dtype == DT_F16) HALLO_RS_T(_Float16);
+  else if (dtype == DT_BF16) HALLO_RS_T(__bf16);
+  else return -22;
+#undef HALLO_RS_T
+#undef HALLO_RS
   HALLO_CHECK_LAUNCH();
   return 0;
 }

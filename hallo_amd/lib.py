@@ -41,6 +41,9 @@ class GemmDesc(C.Structure):
         ("workspace_bytes", C.c_int64),
         ("lead_cols", C.c_int),
         ("lead_alpha", C.c_float),
+        ("ln_colsum", C.c_void_p),
+        ("ln_eps", C.c_float),
+        ("ln_stats", C.c_void_p),
     ]
 
 
@@ -105,6 +108,7 @@ SYMBOLS = {
                                      C.c_void_p]),
     "hallo_nhwc_to_nchw_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float,
                                          C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "hallo_row_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "hallo_face_xattn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "hallo_frames_to_uint8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),

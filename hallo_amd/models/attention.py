@@ -98,6 +98,13 @@ class TemporalBasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.norm3 = LayerNorm(dim)
 
+    def _prepare(self):
+        # LayerNorm is never a kernel in this block: norm1 / norm3 are folded into the q|k|v / GEGLU GEMMs (hallo_gemm
+        # ln_colsum), norm2 into hallo_face_xattn
+        self.attn1._prepare()
+        self.attn1.fold_norm(self.norm1)
+        self.ff.fold_norm(self.norm3)
+
     def run(self, x, enc, bank, video_length, do_cfg, cache=NO_CACHE):
         """x [n = b*f, L, C]; enc [b, T, Cx] face tokens; bank [b*s, L, C] (s = 1 reference + motion frames,
         fp16-rounded: ReferenceAttentionControl.update casts to fp16 whatever the run dtype, :404,452)."""
@@ -110,8 +117,7 @@ class TemporalBasicTransformerBlock(nn.Module):
             return a1.kv(ref.contiguous())
         k2, v2 = cache.get(self, "bank_kv", bank_kv)
 
-        nh = self.norm1.run(x)
-        _, q, k, v = a1.qkv(nh)
+        _, q, k, v = a1.qkv_ln(x)
         # K/V = [self ; bank]: frame row r reads bank entry r % b (the reference's `.repeat(1, f, 1, 1)` on the
         # 3-D tensor tiles the batch axis, mutual_self_attention.py:235-247); with CFG the first half of the
         # rows (uncond) skips the bank segment (:264-284).
@@ -144,7 +150,7 @@ class TemporalBasicTransformerBlock(nn.Module):
             q2 = a2.q(nh.view(n * L, Cd)).view(n, L, Cd)
             a = ops.attention(q2, kf, vf, a2.heads, q_prescaled=True)
             x = a2.out(a, residual=x)
-        return self.ff.run(self.norm3.run(x), residual=x)
+        return self.ff.run_ln(x)
 
 
 class AudioTemporalBasicTransformerBlock(nn.Module):
@@ -184,12 +190,16 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
         cc = [(wz[i] @ xs[i].to_out[0].bias.float())[:, None] for i in range(3)]
         self.w_fused = torch.cat(wc + cc + [torch.zeros((D, 5), device=wc[0].device)], dim=1).to(dt).contiguous()   # [D, 3D+8]
         self.bz3 = torch.stack([c.bias.float() for c in cv])                                                   # [3, D] fp32
+        # the three LayerNorms fold into the GEMMs that consume them (hallo_gemm ln_colsum)
+        self.attn1._prepare()
+        self.attn1.fold_norm(self.norm1)
+        self.ff.fold_norm(self.norm3)
+        self.w_q3_ln, self.g_q3_ln, self.b_q3_ln = ops.fold_layernorm(self.norm2.weight, self.norm2.bias, self.w_q3)
 
     def run(self, x, audio, masks, motion_scale, cache=NO_CACHE):
         """x [n, L, D]; audio [n, 32, Ca]; masks = (full, face, lip), each fp32 [n, L] for this block's depth."""
         n, L, D = x.shape
-        nh = self.norm1.run(x)
-        _, q, k, v = self.attn1.qkv(nh)
+        _, q, k, v = self.attn1.qkv_ln(x)
         a = ops.attention(q, k, v, self.attn1.heads, q_prescaled=True)
         x = self.attn1.out(a, residual=x)
 
@@ -213,12 +223,13 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
         A = cache.get(AudioTemporalBasicTransformerBlock, ("abuf", self.depth, n, L, D), abuf)
         bias_c = cache.get(self, "bias_c", lambda: (torch.tensor(ms, device=x.device)[:, None] * self.bz3).sum(0).to(x.dtype))
 
-        nh = self.norm2.run(x)
-        q3 = ops.gemm(nh.view(n * L, D), self.w_q3, alpha=ops.q_scale(self.attn2_0.dim_head)).view(n, L, 3 * D)
+        x2 = x.view(n * L, D)
+        q3 = ops.gemm(x2, self.w_q3_ln, self.b_q3_ln, alpha=ops.q_scale(self.attn2_0.dim_head), ln_colsum=self.g_q3_ln,
+                      ln_eps=self.norm2.eps, ln_stats=ops.row_stats(x2, self.norm2.eps)).view(n, L, 3 * D)
         # three branches x heads as one attention launch; output rows pre-scaled by motion_scale[i] * mask_i
         # (attention.py:853-903) and written straight into the fused GEMM's A operand
         ops.attention(q3, kv3[:, :, :3 * D], kv3[:, :, 3 * D:], 3 * self.attn2_0.heads,
                       out=A.view(n, L, 3 * D + 8)[:, :, :3 * D], rowscale=msmask, rowscale_head_div=self.attn2_0.heads,
                       q_prescaled=True)
         x = ops.gemm(A, self.w_fused, bias_c, residual=x.view(n * L, D)).view(n, L, D)
-        return self.ff.run(self.norm3.run(x), residual=x)
+        return self.ff.run_ln(x)

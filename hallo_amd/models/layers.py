@@ -194,6 +194,22 @@ class Attention(nn.Module):
         """to_q with the softmax scale folded in (see qkv)."""
         return self.to_q.run(x2d, alpha=ops.q_scale(self.dim_head))
 
+    # -- LayerNorm fused into the projection (hallo_gemm ln_colsum): the block's norm never runs as a kernel ----
+    def fold_norm(self, norm):
+        """Constants for qkv_ln(): LN's affine folded into the fused q|k|v weight (built once per norm, see prepare)."""
+        self._ln_eps = norm.eps
+        self._ln_w, self._ln_g, self._ln_b = ops.fold_layernorm(norm.weight, norm.bias, self.w_qkv, self.b_qkv)
+
+    def qkv_ln(self, x, bias2=None, bias2_rows_per_group=0):
+        """x [N, L, C] UN-normalised -> fused [N, L, 3*inner] of LN(x) (+ bias2: PE @ W^T rows), q pre-scaled."""
+        N, L, Cd = x.shape
+        x2 = x.view(N * L, Cd)
+        y = ops.gemm(x2, self._ln_w, self._ln_b, lead_cols=self.inner, lead_alpha=ops.q_scale(self.dim_head),
+                     ln_colsum=self._ln_g, ln_eps=self._ln_eps, ln_stats=ops.row_stats(x2, self._ln_eps), bias2=bias2,
+                     bias2_rows_per_group=bias2_rows_per_group).view(N, L, 3 * self.inner)
+        i = self.inner
+        return y, y[:, :, :i], y[:, :, i:2 * i], y[:, :, 2 * i:]
+
     def out(self, a, residual=None, **epi):
         """to_out.0 (+ residual) on a [N, L, inner]."""
         N, L, _ = a.shape
@@ -223,6 +239,20 @@ class FeedForward(nn.Module):
         g = self.net[0].proj
         h = ops.gemm(x.view(N * L, Cd), g.weight, g.bias, geglu=True)
         y = self.net[2].run(h, residual=residual.view(N * L, Cd))
+        return y.view(N, L, Cd)
+
+    def fold_norm(self, norm):
+        g = self.net[0].proj
+        self._ln_eps = norm.eps
+        self._ln_w, self._ln_g, self._ln_b = ops.fold_layernorm(norm.weight, norm.bias, g.weight, g.bias)
+
+    def run_ln(self, x):
+        """x [N, L, C] UN-normalised -> ff(LayerNorm(x)) + x, the norm fused into the GEGLU GEMM."""
+        N, L, Cd = x.shape
+        x2 = x.view(N * L, Cd)
+        h = ops.gemm(x2, self._ln_w, self._ln_b, geglu=True, ln_colsum=self._ln_g, ln_eps=self._ln_eps,
+                     ln_stats=ops.row_stats(x2, self._ln_eps))
+        y = self.net[2].run(h, residual=x.view(N * L, Cd))
         return y.view(N, L, Cd)
 
 

@@ -48,16 +48,38 @@ class TemporalTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
         self.ff_norm = LayerNorm(dim)
 
+    def _prepare(self):
+        # LayerNorm + positional encoding fold into the q|k|v GEMM: (LN(h) + PE) W^T = LN-fold(h) + PE W^T, the second term
+        # a per-frame bias row (hallo_gemm bias2); ff_norm folds into the GEGLU GEMM
+        self._ln, self._pe_bias = [], {}
+        for attn, norm in zip(self.attention_blocks, self.norms):
+            attn._prepare()
+            attn.pos_encoder._prepare()
+            self._ln.append(ops.fold_layernorm(norm.weight, norm.bias, attn.w_qkv, attn.b_qkv))
+        self.ff.fold_norm(self.ff_norm)
+
+    def _pe_rows(self, i, attn, batch, frames):
+        """[batch*frames, 3C]: PE[f] @ W_qkv^T, the contribution of the positional encoding to q|k|v of frame f
+        (the reference adds PE to the normed activations, motion_module.py:459,573)."""
+        key = (i, batch, frames)
+        if key not in self._pe_bias:
+            pe = attn.pos_encoder.pe32[:frames].to(attn.w_qkv.dtype)                       # the buffer follows the model dtype
+            rows = ops.gemm(pe.contiguous(), attn.w_qkv)                                   # [frames, 3C]
+            self._pe_bias[key] = rows.repeat(batch, 1).contiguous()
+        return self._pe_bias[key]
+
     def run(self, h, batch, frames):
         """h [batch*frames, L, C]"""
         n, L, Cd = h.shape
-        for attn, norm in zip(self.attention_blocks, self.norms):
-            # LN(h) + PE[frame]: row r = (b*frames + f)*L + pixel -> position (r / L) % frames
-            nh = norm.run(h, pe=attn.pos_encoder.pe32, pe_rows_per_pos=L, pe_len=frames)
-            qkv = ops.gemm(nh.view(n * L, Cd), attn.w_qkv).view(n, L, 3 * Cd)
+        for i, (attn, norm) in enumerate(zip(self.attention_blocks, self.norms)):
+            wf, gcs, bf = self._ln[i]
+            # row r = (b*frames + f)*L + pixel -> bias2 row r / L
+            h2 = h.view(n * L, Cd)
+            qkv = ops.gemm(h2, wf, bf, ln_colsum=gcs, ln_eps=norm.eps, ln_stats=ops.row_stats(h2, norm.eps),
+                           bias2=self._pe_rows(i, attn, batch, frames), bias2_rows_per_group=L).view(n, L, 3 * Cd)
             a = ops.temporal_attention(qkv, batch, frames, L, Cd, attn.heads)
             h = attn.out(a, residual=h)
-        return self.ff.run(self.ff_norm.run(h), residual=h)
+        return self.ff.run_ln(h)
 
 
 class TemporalTransformer3DModel(nn.Module):

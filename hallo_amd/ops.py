@@ -59,7 +59,8 @@ def _workspace(device):
 
 
 def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, act=ACT_NONE, geglu=False,
-         bias2=None, bias2_rows_per_group=0, out_f32=False, bias_per_row=False, lead_cols=0, lead_alpha=1.0):
+         bias2=None, bias2_rows_per_group=0, out_f32=False, bias_per_row=False, lead_cols=0, lead_alpha=1.0,
+         ln_colsum=None, ln_eps=1e-5, ln_stats=None):
     """out[M,N] = act(alpha * rowscale * (a[M,K] @ w[N,K]^T + bias) + residual).
 
     a may be a 2-D view with arbitrary row stride (last dim contiguous).  geglu: w is [2N,K]."""
@@ -92,6 +93,15 @@ def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, 
         d.residual, d.ldr = None, 0
     d.alpha, d.act, d.geglu, d.out_f32 = float(alpha), act, 1 if geglu else 0, 1 if out_f32 else 0
     d.lead_cols, d.lead_alpha = int(lead_cols), float(lead_alpha)
+    if ln_colsum is not None:
+        # fused LayerNorm: `a` is the un-normalised input, w / bias / ln_colsum come from fold_layernorm()
+        assert ln_colsum.dtype == torch.float32 and ln_colsum.is_contiguous() and ln_colsum.numel() == w.shape[0]
+        d.ln_colsum, d.ln_eps = ln_colsum.data_ptr(), float(ln_eps)
+        if ln_stats is not None:
+            assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.numel() == 2 * M
+        d.ln_stats = ln_stats.data_ptr() if ln_stats is not None else None
+    else:
+        d.ln_colsum, d.ln_eps, d.ln_stats = None, 0.0, None
     d.dtype = dtype_code(a.dtype)
     ws = _workspace(a.device)
     d.workspace, d.workspace_bytes = ws.data_ptr(), SPLITK_WS_BYTES
@@ -115,6 +125,7 @@ def gemm_batched(a, w, out, *, out_f32=False, alpha=1.0, bias=None, bias_per_row
     d.bias2, d.bias2_rows_per_group, d.bias2_ld, d.rowscale, d.residual, d.ldr = None, 0, 0, None, None, 0
     d.alpha, d.act, d.geglu, d.out_f32 = float(alpha), ACT_NONE, 0, 1 if out_f32 else 0
     d.lead_cols, d.lead_alpha = 0, 1.0
+    d.ln_colsum, d.ln_eps, d.ln_stats = None, 0.0, None
     d.dtype = dtype_code(a.dtype)
     d.workspace, d.workspace_bytes = None, 0
     _l.check(_l.load().hallo_gemm(C.byref(d), _stream()), "hallo_gemm(batched)")
@@ -367,3 +378,24 @@ def face_xattn_constants(wq, kf, vf, wo, gamma, beta, heads, dtype):
     j = (8 * (2 * ks2 + (e >> 2)) + 4 * hi + (e & 3)).reshape(-1).to(ow.device)
     owp = ow[:, j, :].permute(0, 2, 1).to(dtype).contiguous()            # [nb, C, 32]
     return sg, g, b, owp
+
+
+def fold_layernorm(gamma, beta, w, bias=None):
+    """Constants of the fused LayerNorm GEMM (hallo_gemm ln_colsum): LN(x) @ w^T + bias with LN's affine folded in.
+    Returns (w_f [N, K] in w.dtype = w * gamma, colsum fp32 [N] of the ROUNDED w_f, bias_f [N] = bias + w @ beta)."""
+    wf = (w.float() * gamma.float()[None, :]).to(w.dtype).contiguous()
+    colsum = wf.float().sum(dim=1).contiguous()
+    bf = w.float() @ beta.float()
+    if bias is not None:
+        bf = bf + bias.float()
+    return wf, colsum, bf.to(w.dtype).contiguous()
+
+
+def row_stats(x2d, eps=1e-5):
+    """(mean, rstd) per row of x2d [rows, C] as fp32 [rows, 2]: LayerNorm's statistics for hallo_gemm(ln_stats=...)."""
+    _chk_dev(x2d)
+    assert x2d.dim() == 2 and x2d.is_contiguous()
+    rows, Cd = x2d.shape
+    st = torch.empty((rows, 2), device=x2d.device, dtype=torch.float32)
+    _l.check(_l.load().hallo_row_stats(_p(x2d), _p(st), rows, Cd, float(eps), dtype_code(x2d.dtype), _stream()), "hallo_row_stats")
+    return st

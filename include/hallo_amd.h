@@ -85,6 +85,15 @@ typedef struct hallo_gemm_desc {
    * hallo_attention(q_prescaled = 1) exponentiates raw scores. */
   int lead_cols;
   float lead_alpha;
+  /* ABI v2: fused LayerNorm (nn.LayerNorm in front of to_q|to_k|to_v, to_q, GEGLU: hallo/models/attention.py:563-601,
+   * 784-905; motion_module.py:387-423).  When ln_colsum != NULL, A is the UN-normalised activation, W must be
+   * gamma-scaled (W[n,k] * gamma[k], rounded once), bias must include beta . W^T, and ln_colsum[n] = sum_k W[n,k] of
+   * the scaled, rounded W in fp32 ([N]; geglu: [2N]).  The kernel reduces every row of A to mean / rstd over K while it
+   * feeds the MFMAs and writes act(alpha * ... (rstd * (acc - mean * ln_colsum[n]) + bias + bias2) ...): LayerNorm costs
+   * no pass over HBM.  batch = 1, dtype output, no bias_per_row. */
+  const float* ln_colsum;
+  float ln_eps;
+  const float* ln_stats;     /* optional [M][2] fp32 (mean, rstd) from hallo_row_stats; NULL: computed inside the K loop */
 } hallo_gemm_desc;
 int hallo_gemm(const hallo_gemm_desc* d, void* stream);
 
@@ -216,6 +225,11 @@ int hallo_timestep_embedding(const float* t, void* out, int batch, int dim, int 
 int hallo_cfg_ddim_step(const void* model_out, int64_t ldm, float* latents, void* next_in, int64_t ldn,
                         int rows, int C, int cfg, float guidance_scale, float alpha_t, float alpha_prev,
                         int dtype, void* stream);
+
+/* hallo_row_stats: per-row LayerNorm statistics stats[r] = (mean, 1/sqrt(var + eps)) of x [rows, C] (two-pass, fp32),
+ * the only pass over x that nn.LayerNorm still costs when its affine is folded into the consuming hallo_gemm
+ * (ln_colsum / ln_stats).  C % 8 == 0, C <= 1536. */
+int hallo_row_stats(const void* x, float* stats, int64_t rows, int C, float eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * hallo_face_xattn: y = x + to_out(SDPA(to_q(LayerNorm(x)), K_face, V_face)) for a cross-attention over H*T = 32

@@ -115,6 +115,61 @@ def test_gemm_epilogues(dtype, report):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(4096, 960, 320), (1000, 328, 640), (70, 1920, 1280), (8192, 320, 320)])
+def test_gemm_fused_layernorm(dtype, M, N, K, report):
+    """nn.LayerNorm fused into the consuming projection (hallo_gemm ln_colsum): the kernel sees the un-normalised rows,
+    reduces them to mean / rstd next to the MFMAs and applies rstd * (acc - mean * colsum) + bias; compared with
+    layer_norm(x) @ W^T + b in fp32, with non-zero row means, a leading-column scale and a per-frame bias (the motion
+    module's PE @ W^T rows)."""
+    from hallo_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _rand((M, K), dtype, g) * 1.5 + 0.7
+    gamma = (1.0 + 0.1 * torch.randn((K,), generator=g)).to(dtype).to(_dev())
+    beta = _rand((K,), dtype, g, 0.1)
+    w = _rand((N, K), dtype, g, K ** -0.5)
+    b = _rand((N,), dtype, g, 0.1)
+    wf, cs, bf = ops.fold_layernorm(gamma, beta, w, b)
+    nh = torch.nn.functional.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5)
+    ref = nh @ w.float().t() + b.float()
+    out = ops.gemm(x, wf, bf, ln_colsum=cs, ln_eps=1e-5)                      # statistics inside the K loop
+    _check(f"gemm_ln[{M},{N},{K}]", out, ref, dtype, report)
+    st = ops.row_stats(x, 1e-5)                                              # statistics from hallo_row_stats
+    xf = x.float()
+    assert torch.allclose(st[:, 0], xf.mean(1), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(st[:, 1], (xf.var(1, unbiased=False) + 1e-5).rsqrt(), atol=1e-4, rtol=1e-3)
+    out = ops.gemm(x, wf, bf, ln_colsum=cs, ln_eps=1e-5, ln_stats=st)
+    _check(f"gemm_ln_stats[{M},{N},{K}]", out, ref, dtype, report)
+    lead = (N // 3) // 8 * 8
+    b2 = _rand(((M + 63) // 64, N), dtype, g)
+    out = ops.gemm(x, wf, bf, ln_colsum=cs, ln_eps=1e-5, lead_cols=lead, lead_alpha=0.25, bias2=b2, bias2_rows_per_group=64)
+    ref2 = ref + b2.float().repeat_interleave(64, 0)[:M]
+    ref2[:, :lead] *= 0.25
+    _check(f"gemm_ln_lead_bias2[{M},{N},{K}]", out, ref2, dtype, report)
+    res = _rand((M, N), dtype, g)
+    out = ops.gemm(x, wf, bf, ln_colsum=cs, ln_eps=1e-5, residual=res)
+    _check(f"gemm_ln_res[{M},{N},{K}]", out, ref + res.float(), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Cd", [(300, 320), (2048, 640)])
+def test_gemm_geglu_fused_layernorm(dtype, M, Cd, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(77 + Cd)
+    x = _rand((M, Cd), dtype, g) * 1.3 - 0.4
+    gamma = (1.0 + 0.1 * torch.randn((Cd,), generator=g)).to(dtype).to(_dev())
+    beta = _rand((Cd,), dtype, g, 0.1)
+    w = _rand((8 * Cd, Cd), dtype, g, Cd ** -0.5)
+    b = _rand((8 * Cd,), dtype, g, 0.1)
+    wf, cs, bf = ops.fold_layernorm(gamma, beta, w, b)
+    nh = torch.nn.functional.layer_norm(x.float(), (Cd,), gamma.float(), beta.float(), 1e-5)
+    out = ops.gemm(x, wf, bf, geglu=True, ln_colsum=cs, ln_eps=1e-5)
+    _check(f"geglu_ln[{M},{Cd}]", out, ops_ref.geglu(nh, w, b), dtype, report)
+    out = ops.gemm(x, wf, bf, geglu=True, ln_colsum=cs, ln_eps=1e-5, ln_stats=ops.row_stats(x, 1e-5))
+    _check(f"geglu_ln_stats[{M},{Cd}]", out, ops_ref.geglu(nh, w, b), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,Cd", [(300, 320), (1024, 640)])
 def test_gemm_geglu(dtype, M, Cd, report):
     from hallo_amd import ops
