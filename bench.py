@@ -61,10 +61,12 @@ class OpProfiler:
         dt = "__bf16" if self.dtype == torch.bfloat16 else "_Float16"
         if name in ("gemm", "conv3x3"):
             c = ops.get_option("last_gemm_kernel")
-            kern, mode, sub = c // 100, (c // 10) % 10, c % 10
+            lnf, kern, mode, sub = c // 1000, (c // 100) % 10, (c // 10) % 10, c % 10
             if kern == 1:
                 return "gemm_kernel<%s,%s,%s>" % (dt, "true" if mode == 1 else "false", "true" if mode == 2 else "false")
-            return "gemm%d_kernel<%s,%d,%d>" % (kern, dt, mode, sub)
+            if kern == 2:
+                return "gemm2_kernel<%s,%d,%d,%d>" % (dt, mode, sub, lnf)
+            return "gemm3_kernel<%s,%d,%d,%s>" % (dt, mode, sub & 3, "true" if sub & 4 else "false")
         if name == "attention":
             hd = a[0].shape[-1] // a[3]
             return "attn_kernel<%s,%d,%s>" % (dt, hd, "true" if k.get("q_prescaled") else "false")
@@ -406,8 +408,11 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
             t = tj.get(name.split("<")[0])
             if t:
-                traffic = {"fetch_bytes_per_launch": round(t["fetch_bytes_per_launch"]), "write_bytes_per_launch": round(t["write_bytes_per_launch"]),
-                           "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]), "source": tj.get("_source", "profiles/r1_pmc_traffic.json")}
+                wr = t.get("write_bytes_per_launch")
+                traffic = {"fetch_bytes_per_launch": round(t["fetch_bytes_per_launch"]),
+                           "write_bytes_per_launch": round(wr) if wr is not None else None,
+                           "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+                           "source": t.get("note") or tj.get("_source", "profiles/r1_pmc_traffic.json")}
         except Exception:
             pass
         # bound by arithmetic intensity against the machine balance (2500 TFLOP/s / 8 TB/s = 312 flop/B): the K = 320

@@ -763,7 +763,8 @@ static int g_split_k = 1;        // 0: never split K, 1: auto
 static int g_conv_fast = 1;      // 0: always use the general (per-thread tap) conv gather
 static int g_v3_min_tiles = 192; // auto: smallest grid (workgroups, 1 per CU) worth the big-tile kernel
 // Kernel picked by the last hallo_gemm / hallo_conv3x3_nhwc call, for per-symbol profiling (bench.py):
-// 100 * kernel (1 gemm_kernel, 2 gemm2_kernel, 3 gemm3_kernel) + 10 * mode (0 gemm, 1 conv, 2 geglu) + stages / TM
+// 1000 * LNF (gemm2: 0 none, 1 in-loop LayerNorm statistics, 2 external) + 100 * kernel (1 gemm_kernel, 2 gemm2_kernel,
+// 3 gemm3_kernel) + 10 * mode (0 gemm, 1 conv, 2 geglu) + stages / TM (+ 4 for the persistent gemm3 mode)
 static int g_last_kernel = 0;
 
 
@@ -856,7 +857,8 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     }
   }
   dim3 grid(tiles, a.splits, batch), block(256);
-  g_last_kernel = (v == 0 ? 100 : 200) + 10 * (geglu ? 2 : (conv ? 1 : 0)) + (v == 0 ? 0 : v);
+  g_last_kernel = (v == 0 ? 100 : 200) + 10 * (geglu ? 2 : (conv ? 1 : 0)) + (v == 0 ? 0 : v) +
+                  1000 * (v != 0 && lnf ? (a.ln_stats ? 2 : 1) : 0);
   if (v == 0) {
     if (geglu) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, st, a);
     else if (conv) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, 0, st, a);
