@@ -17,7 +17,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 enum { DT_F16 = 0, DT_BF16 = 1 };
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };
+// ACT_GELU: erf GELU after the residual add (wav2vec2 feed-forward / conv feature layers); ACT_GELU_PRE: GELU of
+// alpha * (acc + bias) BEFORE the residual add (wav2vec2 positional conv: hidden + gelu(conv(hidden))).
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_GELU = 3, ACT_GELU_PRE = 4 };
 
 template <typename T> struct Vec;
 template <> struct Vec<_Float16> {

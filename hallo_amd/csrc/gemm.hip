@@ -214,9 +214,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         if (bias2) v += to_f32(bias2[(long)(m / p.bias2_rpg) * p.bias2_ld + n]);
         if (p.rowscale) v *= p.rowscale[m];
         v *= (n < p.lead_cols) ? p.alpha * p.lead_alpha : p.alpha;
+        if (p.act == ACT_GELU_PRE) v = gelu_erf_f(v);
         if (res) v += to_f32(res[(long)m * p.ldr + n]);
         if (p.act == ACT_SILU) v = silu_f(v);
         else if (p.act == ACT_RELU) v = fmaxf(v, 0.0f);
+        else if (p.act == ACT_GELU) v = gelu_erf_f(v);
         if (p.out_f32) Cf[(long)m * p.ldc + n] = v;
         else C[(long)m * p.ldc + n] = from_f32<T>(v);
       }
@@ -255,11 +257,13 @@ constexpr int TILE_ELEMS = 128 * 64;
 // (hallo_row_stats: one read pass over A) -- cheaper whenever several N tiles share a row block, because every tile
 // would otherwise redo the statistics of the same rows (measured: the in-loop form makes the N = 2560 GEGLU GEMMs
 // 25 % slower, more than the LayerNorm launch it replaces).
-template <typename T, int MODE /*0 gemm, 1 conv3x3, 2 geglu*/, int STAGES, int LNF>
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 ? 3 : 4)) void gemm2_kernel(const GemmArgs p) {
+template <typename T, int MODE /*0 gemm, 1 conv3x3, 2 geglu, 3 gemm with a GELU epilogue*/, int STAGES, int LNF>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 || MODE == 3 ? 3 : 4)) void gemm2_kernel(const GemmArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
-  constexpr bool CONV = MODE == 1, GEGLU = MODE == 2;
+  // MODE 3 is a separate instantiation so that the erf polynomial's registers never burden the hot MODE 0 kernel
+  // (it sits exactly at the 128-VGPR / 4-waves-per-SIMD boundary)
+  constexpr bool CONV = MODE == 1, GEGLU = MODE == 2, GELU = MODE == 3;
   __shared__ __attribute__((aligned(16))) T smem[STAGES * 2 * TILE_ELEMS];
 
   const int tid = threadIdx.x;
@@ -663,6 +667,10 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 ? 3 : 4)) void ge
           const float rs = (p.rowscale ? p.rowscale[m] * p.alpha : p.alpha) * ((n < p.lead_cols) ? p.lead_alpha : 1.0f);
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] *= rs;
+          if (GELU && p.act == ACT_GELU_PRE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = gelu_erf_f(o[j]);
+          }
           if (use_res) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += to_f32(rpre[i][j]);
@@ -677,6 +685,9 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 ? 3 : 4)) void ge
           } else if (p.act == ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.0f);
+          } else if (GELU && p.act == ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = gelu_erf_f(o[j]);
           }
           if (p.out_f32) {
             float* cp = Cf + (long)m * p.ldc + n;
@@ -727,6 +738,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   const float rs = (p.rowscale ? p.rowscale[m] * p.alpha : p.alpha) * ((n < p.lead_cols) ? p.lead_alpha : 1.0f);
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] *= rs;
+  if (p.act == ACT_GELU_PRE) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = gelu_erf_f(o[j]);
+  }
   if (res) {
     const T* rp = res + (long)m * p.ldr + n;
     if (p.res_vec_ok) {
@@ -742,6 +757,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   for (int j = 0; j < 8; ++j) {
     if (p.act == ACT_SILU) o[j] = silu_f(o[j]);
     else if (p.act == ACT_RELU) o[j] = fmaxf(o[j], 0.0f);
+    else if (p.act == ACT_GELU) o[j] = gelu_erf_f(o[j]);
   }
   if (p.out_f32) {
     float* cp = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
@@ -774,6 +790,11 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
   a.splits = 1; a.nk_per_split = 0; a.slab = nullptr;
   int v = a.vec_ok ? g_gemm_variant : 0;
   const bool lnf = a.ln_colsum != nullptr;      // fused LayerNorm: 128x128 LDS-DMA kernel only, no split-K
+  const bool gelu = a.act >= ACT_GELU;          // GELU epilogues (wav2vec2 front-end): own instantiation of the 128x128 kernel
+  if (gelu) {
+    if (conv || geglu || lnf) return -22;
+    if (v >= 4) v = 3;
+  }
   if (lnf) {
     if (!a.vec_ok || conv) return -22;
     v = (v == 1 || v == 2) ? v : 3;
@@ -857,7 +878,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     }
   }
   dim3 grid(tiles, a.splits, batch), block(256);
-  g_last_kernel = (v == 0 ? 100 : 200) + 10 * (geglu ? 2 : (conv ? 1 : 0)) + (v == 0 ? 0 : v) +
+  g_last_kernel = (v == 0 ? 100 : 200) + 10 * (geglu ? 2 : (conv ? 1 : (gelu && v != 0 ? 3 : 0))) + (v == 0 ? 0 : v) +
                   1000 * (v != 0 && lnf ? (a.ln_stats ? 2 : 1) : 0);
   if (v == 0) {
     if (geglu) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, 0, st, a);
@@ -869,6 +890,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     else if (lnf && geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 1, 1>), grid, block, 0, st, a);
     else if (lnf) hipLaunchKernelGGL((gemm2_kernel<T, 0, 1, 1>), grid, block, 0, st, a);
     else if (geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 1, 0>), grid, block, 0, st, a);
+    else if (gelu) hipLaunchKernelGGL((gemm2_kernel<T, 3, 1, 0>), grid, block, 0, st, a);
     else if (conv) hipLaunchKernelGGL((gemm2_kernel<T, 1, 1, 0>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((gemm2_kernel<T, 0, 1, 0>), grid, block, 0, st, a);
   } else {
@@ -877,6 +899,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     else if (lnf && geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 2, 1>), grid, block, 0, st, a);
     else if (lnf) hipLaunchKernelGGL((gemm2_kernel<T, 0, 2, 1>), grid, block, 0, st, a);
     else if (geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 2, 0>), grid, block, 0, st, a);
+    else if (gelu) hipLaunchKernelGGL((gemm2_kernel<T, 3, 2, 0>), grid, block, 0, st, a);
     else if (conv) hipLaunchKernelGGL((gemm2_kernel<T, 1, 2, 0>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((gemm2_kernel<T, 0, 2, 0>), grid, block, 0, st, a);
   }
@@ -907,6 +930,7 @@ extern "C" int hallo_gemm(const hallo_gemm_desc* d, void* stream) {
   if (!d || !d->A || !d->B || !d->C) return -22;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K & 7)) return -22;
   if (d->batch < 1) return -22;
+  if (d->act < ACT_NONE || d->act > ACT_GELU_PRE) return -22;
   if ((d->lda & 7) || (d->ldb & 7)) return -22;
   if (d->geglu && (d->rowscale || d->residual || d->bias2 || d->out_f32 || d->bias_per_row || d->lead_cols > 0)) return -22;
   GemmArgs a;

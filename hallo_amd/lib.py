@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhallo_amd.so")
 
 F16, BF16 = 0, 1
-ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_GELU, ACT_GELU_PRE = 0, 1, 2, 3, 4
 
 
 class HalloLibraryError(RuntimeError):
@@ -112,6 +112,10 @@ SYMBOLS = {
     "hallo_face_xattn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "hallo_frames_to_uint8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "hallo_w2v_conv0_workspace": (C.c_int64, [C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "hallo_w2v_conv0_gn_gelu": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "hallo_lerp_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hallo_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hallo_cfg_ddim_step": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),

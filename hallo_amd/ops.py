@@ -12,6 +12,7 @@ from . import lib as _l
 
 F16, BF16 = _l.F16, _l.BF16
 ACT_NONE, ACT_SILU, ACT_RELU = _l.ACT_NONE, _l.ACT_SILU, _l.ACT_RELU
+ACT_GELU, ACT_GELU_PRE = _l.ACT_GELU, _l.ACT_GELU_PRE
 
 
 def dtype_code(dtype):
@@ -109,9 +110,14 @@ def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, 
     return out
 
 
-def gemm_batched(a, w, out, *, out_f32=False, alpha=1.0, bias=None, bias_per_row=False):
-    """Strided-batched out[b] = alpha * (a[b] @ w[b]^T + bias); a [B,M,K], w [B,N,K], out [B,M,N]."""
+def gemm_batched(a, w, out, *, out_f32=False, alpha=1.0, bias=None, bias_per_row=False, bias_stride=None, act=ACT_NONE,
+                 residual=None):
+    """Strided-batched out[b] = act(alpha * (a[b] @ w[b]^T + bias) + residual[b]); a [B,M,K], w [B,N,K], out [B,M,N]
+    (3-D views: any batch / row stride, last dim contiguous).  `bias` is shared by the batch entries; `residual` is a
+    view shaped like `out`."""
     _chk_dev(a, w, out)
+    assert bias_stride is None, "per-batch bias is not part of the C ABI"
+    assert a.stride(2) == 1 and w.stride(2) == 1 and out.stride(2) == 1
     Bn, M, K = a.shape
     N = w.shape[1]
     d = _l.GemmDesc()
@@ -123,7 +129,10 @@ def gemm_batched(a, w, out, *, out_f32=False, alpha=1.0, bias=None, bias_per_row
     d.bias = bias.data_ptr() if bias is not None else None
     d.bias_per_row = 1 if bias_per_row else 0
     d.bias2, d.bias2_rows_per_group, d.bias2_ld, d.rowscale, d.residual, d.ldr = None, 0, 0, None, None, 0
-    d.alpha, d.act, d.geglu, d.out_f32 = float(alpha), ACT_NONE, 0, 1 if out_f32 else 0
+    if residual is not None:
+        assert residual.shape == out.shape and residual.stride(2) == 1
+        d.residual, d.ldr, d.stride_r = residual.data_ptr(), residual.stride(1), residual.stride(0)
+    d.alpha, d.act, d.geglu, d.out_f32 = float(alpha), act, 0, 1 if out_f32 else 0
     d.lead_cols, d.lead_alpha = 0, 1.0
     d.ln_colsum, d.ln_eps, d.ln_stats = None, 0.0, None
     d.dtype = dtype_code(a.dtype)
@@ -399,3 +408,40 @@ def row_stats(x2d, eps=1e-5):
     st = torch.empty((rows, 2), device=x2d.device, dtype=torch.float32)
     _l.check(_l.load().hallo_row_stats(_p(x2d), _p(st), rows, Cd, float(eps), dtype_code(x2d.dtype), _stream()), "hallo_row_stats")
     return st
+
+
+_w2v_ws = {}
+
+
+def w2v_conv0_gn_gelu(wave, w, gamma, beta, k, stride, eps, dtype):
+    """First wav2vec2 feature-encoder layer: fp32 waveform [S] -> [L0, C] = GELU(GroupNorm_C(Conv1d(1 -> C, k, stride)))
+    in `dtype` (transformers Wav2Vec2GroupNormConvLayer; see include/hallo_amd.h: hallo_w2v_conv0_gn_gelu)."""
+    _chk_dev(wave, w)
+    assert wave.dtype == torch.float32 and wave.dim() == 1 and wave.is_contiguous()
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] == k
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    Cd, S = w.shape[0], wave.numel()
+    lib = _l.load()
+    need = lib.hallo_w2v_conv0_workspace(S, Cd, k, stride)
+    if need < 0:
+        raise _l.HalloLibraryError(f"hallo_w2v_conv0_workspace({S}, {Cd}, {k}, {stride}) failed with status {need}")
+    key = (wave.device, torch.cuda.current_stream().cuda_stream)
+    ws = _w2v_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(max(need // 4, 1 << 16), device=wave.device, dtype=torch.float32)
+        _w2v_ws[key] = ws
+    L0 = (S - k) // stride + 1
+    out = torch.empty((L0, Cd), device=wave.device, dtype=dtype)
+    _l.check(lib.hallo_w2v_conv0_gn_gelu(_p(wave), S, _p(w), _p(gamma), _p(beta), _p(out), _p(ws), Cd, k, stride, float(eps),
+                                         dtype_code(dtype), _stream()), "hallo_w2v_conv0_gn_gelu")
+    return out
+
+
+def lerp_rows(x, out_rows):
+    """x [L, C] -> [out_rows, C]: F.interpolate(mode="linear", align_corners=True) along the row (time) axis."""
+    _chk_dev(x)
+    assert x.dim() == 2 and x.is_contiguous()
+    out = torch.empty((out_rows, x.shape[1]), device=x.device, dtype=x.dtype)
+    _l.check(_l.load().hallo_lerp_rows(_p(x), _p(out), x.shape[0], out_rows, x.shape[1], dtype_code(x.dtype), _stream()),
+             "hallo_lerp_rows")
+    return out

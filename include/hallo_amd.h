@@ -30,6 +30,8 @@ extern "C" {
 #define HALLO_ACT_NONE 0
 #define HALLO_ACT_SILU 1
 #define HALLO_ACT_RELU 2
+#define HALLO_ACT_GELU 3      /* erf GELU after the residual add (hallo_gemm only) */
+#define HALLO_ACT_GELU_PRE 4  /* erf GELU of alpha * (acc + bias), BEFORE the residual add (hallo_gemm only) */
 
 int hallo_abi_version(void);
 
@@ -253,6 +255,27 @@ int hallo_face_xattn(const void* x, void* y, const void* sg, const float* g, con
  * that the D2H copy / the 8-GPU all-gather of a clip moves 4x fewer bytes.
  */
 int hallo_frames_to_uint8(const float* x, uint8_t* y, int frames, int channels, int64_t hw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ABI v3: wav2vec2 audio front-end: Wav2VecModel.forward (hallo/models/wav2vec.py:42-109) =
+ * transformers Wav2Vec2FeatureEncoder -> linear_interpolation to the video frame rate (wav2vec.py:196-209) ->
+ * Wav2Vec2FeatureProjection -> Wav2Vec2Encoder with all 12 hidden states kept (audio_processor.py:105-129).
+ *
+ * hallo_w2v_conv0_gn_gelu: the first feature-encoder layer, Conv1d(1 -> C, k, stride, bias = False) ->
+ *   GroupNorm(C groups: per-channel statistics over time, biased variance) -> erf GELU, on a normalised fp32 waveform
+ *   wave[n_samples].  y is the token-major activation [L0, C] in `dtype`, L0 = (n_samples - k) / stride + 1.
+ *   w is fp32 [C][k] (conv.weight[:, 0, :]), gamma / beta fp32 [C].  The conv is recomputed, not stored: pass 1 reduces
+ *   the statistics (deterministic two-level reduction, combined in fp64), pass 2 normalises and writes y once.
+ *   workspace: hallo_w2v_conv0_workspace(n_samples, C, k, stride) bytes of fp32 scratch.
+ *   C % 8 == 0, k <= 16, stride <= 8.  The remaining feature-encoder layers are hallo_gemm calls over overlapping row
+ *   windows of y (lda = stride * C, K = k * C) with act = HALLO_ACT_GELU.
+ * hallo_lerp_rows: y[t, :] = lerp of x rows at src = t * (in_rows - 1) / (out_rows - 1), i.e.
+ *   F.interpolate(mode = "linear", align_corners = True) along time with ATen's fp32 index arithmetic. C % 8 == 0.
+ */
+int64_t hallo_w2v_conv0_workspace(int64_t n_samples, int C, int k, int stride);
+int hallo_w2v_conv0_gn_gelu(const float* wave, int64_t n_samples, const float* w, const float* gamma, const float* beta,
+                            void* y, float* workspace, int C, int k, int stride, float eps, int dtype, void* stream);
+int hallo_lerp_rows(const void* x, void* y, int in_rows, int out_rows, int C, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

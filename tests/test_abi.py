@@ -19,12 +19,12 @@ def lib():
 def test_header_symbols_are_exported(lib):
     from hallo_amd import lib as hl
     hdr = open(os.path.join(ROOT, "include", "hallo_amd.h")).read()
-    declared = set(re.findall(r"^int\s+(hallo_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t)\s+(hallo_\w+)\s*\(", hdr, flags=re.M))
     assert declared, "no declarations parsed from include/hallo_amd.h"
     assert declared == set(hl.SYMBOLS), (declared ^ set(hl.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hallo_abi_version() == 2
+    assert lib.hallo_abi_version() == 3
 
 
 def test_struct_sizes_match_header(lib):
