@@ -294,6 +294,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B: hallo_set_option('gemm_variant', v) (default: library auto)")
     ap.add_argument("--shape-breakdown", action="store_true", help="write gpurun_out/shape_breakdown.json (per op x shape times)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="CONTROL-FLOW TEST ONLY (tests/test_multigpu_cpu.py): gloo on CPU, the clip is a stub, the JSON line is "
+                         "marked as not a measurement; exercises rank layout, fences, the frame all-gather and the rank-0-only legs")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.frames, args.ddim_steps, args.cpu_budget)
@@ -303,39 +306,58 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dry = args.dry_run_cpu
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+    if dry:
+        dev = torch.device("cpu")
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
-    from hallo_amd import lib
-    lib.load()
-    if args.gemm_variant is not None:
-        from hallo_amd import ops as _ops
-        _ops.set_option("gemm_variant", args.gemm_variant)
-    from hallo_amd.synthetic import build_pipeline, clip_inputs
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    pipe, audioproj = build_pipeline(dev, dtype)
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     S, Fr = args.size, args.frames
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    if not dry:
+        from hallo_amd import lib
+        lib.load()
+        if args.gemm_variant is not None:
+            from hallo_amd import ops as _ops
+            _ops.set_option("gemm_variant", args.gemm_variant)
+        from hallo_amd.synthetic import build_pipeline, clip_inputs
+        pipe, audioproj = build_pipeline(dev, dtype)
     from hallo_amd.animate.clip_parallel import gather_wave
     # rank 0 receives the whole wave (one clip per rank) and copies ALL of it to the host
-    host = torch.empty((world if rank == 0 else 1, Fr, 3, S * S), dtype=torch.float32).pin_memory()
+    host = torch.empty((world if rank == 0 else 1, Fr, 3, S * S), dtype=torch.float32)
+    if not dry:
+        host = host.pin_memory()
 
     def one_clip(idx):
+        if dry:
+            return {"stub": float(rank * 1000 + idx)}
         d = clip_inputs(S, Fr, seed=1234 + rank * 1000 + idx, device=dev)
-        torch.cuda.synchronize()
+        sync()
         return d
 
-    def run(d):
-        audio = audioproj(d["audio_emb"])
-        lat = pipe(d["ref_image"], d["face_emb"], audio, d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr,
-                   args.ddim_steps, args.guidance, motion_scale=d["motion_scale"], latents=d["latents"], decode=False)
-        h = S // 8
-        lat = lat[0].permute(1, 2, 3, 0).reshape(Fr * h * h, 4).contiguous()
-        frames, _, _ = pipe.decode_latents_device(lat, Fr, h, h)
-        if world > 1:
+    def run(d, exchange=True):
+        if dry:
+            frames = torch.full((Fr, 3, S * S), d["stub"])
+        else:
+            audio = audioproj(d["audio_emb"])
+            lat = pipe(d["ref_image"], d["face_emb"], audio, d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr,
+                       args.ddim_steps, args.guidance, motion_scale=d["motion_scale"], latents=d["latents"], decode=False)
+            h = S // 8
+            lat = lat[0].permute(1, 2, 3, 0).reshape(Fr * h * h, 4).contiguous()
+            frames, _, _ = pipe.decode_latents_device(lat, Fr, h, h)
+        if world > 1 and exchange:
             g = gather_wave(frames)                            # RCCL all-gather of decoded frames, clip order = rank
             if rank == 0:
                 host.copy_(g, non_blocking=True)
@@ -348,10 +370,10 @@ def main():
         run(inputs[i])
 
     def fence():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            sync()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -375,10 +397,15 @@ def main():
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (" + RCCL all-gather of frames" if world > 1 else "")},
     }
 
-    if rank == 0 and not args.no_profile:
+    if dry:
+        out["data"] = "DRY RUN on CPU (control-flow test, the clip is a stub): NOT a measurement"
+        out["dry_run_wave"] = [float(v) for v in host[:, 0, 0, 0]] if rank == 0 else None
+        if rank == 0:
+            run(inputs[-1], exchange=False)     # the rank-0-only instrumented leg of the real run
+    elif rank == 0 and not args.no_profile:
         prof = OpProfiler()
         prof.install(dtype)
-        run(inputs[-1])
+        run(inputs[-1], exchange=False)     # rank 0 alone: the instrumented clip must not enter a collective
         fam = prof.summary()
         prof.remove()
         if args.shape_breakdown:
@@ -434,7 +461,7 @@ def main():
                                 "tflops": round(a["tflops"], 1), "mfma_frac": round(a["tflops"] / PEAK_BF16_TFLOPS, 4)}
         out["end_to_end_mfma_frac"] = round(tot_flop / 1e12 / (elapsed / args.steps) / PEAK_BF16_TFLOPS, 4)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         try:
             out["cpu_baseline"] = cpu_baseline(Fr, args.ddim_steps, args.cpu_budget)
             if out["cpu_baseline"]["value"]:

@@ -52,3 +52,36 @@ def test_sharding_is_a_partition():
             got = sorted(sum((cp.clips_of_rank(n, r, w) for r in range(w)), []))
             assert got == list(range(n))
             assert cp.n_waves(n, w) == -(-n // w)
+
+
+def test_bench_control_flow_world2(tmp_path):
+    """bench.py launched the way the driver launches N > 1 (torch.distributed.run, one process per rank), on CPU with
+    gloo and a stub clip (--dry-run-cpu): the fences, the per-step frame all-gather, the max-over-ranks time and the
+    rank-0-only legs after the timed region must not deadlock, and rank 0 must print exactly one JSON line."""
+    import json
+    import subprocess
+    port = 29600 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--dry-run-cpu", "--size", "16", "--frames", "4"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert "NOT a measurement" in out["data"]
+    # the last timed wave as rank 0 received it: clip of rank 0 then clip of rank 1 (stub value = rank * 1000 + clip index)
+    assert out["dry_run_wave"] == [3.0, 1003.0]
+    assert abs(out["value"] - 2 * 3 * 4 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+
+
+def test_bench_control_flow_world1():
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-cpu", "--size", "16", "--frames", "4"],
+                       capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["dry_run_wave"] == [2.0]
