@@ -23,7 +23,10 @@ import os
 import sys
 import time
 
-import torch
+# the host driver of the GPU pool only supports dmabuf IPC: RCCL's cross-process buffer sharing needs this (N > 1)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
