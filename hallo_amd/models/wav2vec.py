@@ -354,3 +354,22 @@ class Wav2VecModel(HalloModule):
         """wav2vec.py:42-109."""
         feats = self.feature_extract(input_values, seq_len)
         return self.encode(feats, attention_mask, mask_time_indices, output_attentions, output_hidden_states, return_dict)
+
+
+@torch.no_grad()
+def fill_synthetic_(model, seed=0):
+    """Deterministic random-init weights for benches / smoke runs (no checkpoint exists offline): fan-in scaled normals,
+    norm affines near (1, 0), weight-norm gains near 1."""
+    g = torch.Generator().manual_seed(seed)
+    for name, p in model.named_parameters():
+        if name.endswith("weight_g"):
+            v = 1.0 + 0.25 * torch.rand(p.shape, generator=g)
+        elif "norm.weight" in name:
+            v = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
+        elif p.dim() == 1:
+            v = 0.1 * torch.randn(p.shape, generator=g)
+        else:
+            v = torch.randn(p.shape, generator=g) * (2.0 / p[0].numel()) ** 0.5
+        p.copy_(v.to(device=p.device, dtype=p.dtype))
+    model._prepared = False
+    return model
