@@ -1,0 +1,163 @@
+"""Host logic of the native models on CPU: the hallo_amd models run with the kernel-backed entry points of hallo_amd.ops
+replaced by tests/emu_ops.py (a torch emulation of the C ABI's documented semantics, fp32) and are compared with the CPU
+oracle on identical weights.  What this pins without a GPU: weight images, fused q|k|v / audio / face cross-attention
+constants, LayerNorm folding, bank routing and the CFG uncond rule, motion-frame handling, the block drivers' as-shipped
+branch semantics, CFG + DDIM plumbing, VAE, conditioners, the sliding-window driver.  fp32 on both sides, so the tolerance
+is reassociation noise (1e-4 relative), three orders below the GPU tolerances: an algebra mistake cannot hide in it.
+The HIP kernels are NOT exercised here (tests/test_*_gpu.py do that through the real library)."""
+import pytest
+import torch
+
+TOL = 2e-4
+
+
+@pytest.fixture()
+def emu(monkeypatch):
+    import emu_ops
+    return emu_ops.install(monkeypatch)
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import harness as Hn
+    return Hn.oracle_nets(dtype=torch.float32)
+
+
+def _native(oracle):
+    from oracle import harness as Hn
+    return Hn.native_nets(oracle, dtype=torch.float32, device="cpu")
+
+
+def _banks(o, n, B, h):
+    g = torch.Generator().manual_seed(5)
+    ref_lat = torch.randn((3, 4, h, h), generator=g)
+    enc = torch.randn((B, 4, 64), generator=g)
+    with torch.no_grad():
+        ob = o["reference_unet"](ref_lat.repeat(B, 1, 1, 1), torch.tensor(0), enc)
+    n["reference_unet"](ref_lat.repeat(B, 1, 1, 1), 0, enc)
+    return ref_lat, enc, ob, n["reference_unet"].written_banks
+
+
+@pytest.mark.parametrize("do_cfg", [False, True])
+def test_referencenet_and_unet3d_forward(emu, oracle, do_cfg):
+    from oracle import harness as Hn
+    from hallo_amd.models.mutual_self_attention import ReferenceAttentionControl
+    o, n = oracle, _native(oracle)
+    B, Fr, h = (2 if do_cfg else 1), 4, 16
+    _, enc, ob, nb = _banks(o, n, B, h)
+    assert len(ob) == len(nb) == 16
+    assert max(Hn.rel_l2(a, b) for a, b in zip(nb, ob)) < TOL
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(s, generator=g)
+    lat, audio, fm = r(B, 4, Fr, h, h), r(B, Fr, 32, Hn.SMALL_AUDIO_DIM), r(B, 80, Fr, h, h)
+    masks = lambda: [torch.rand((B * Fr, (h // 2 ** l) ** 2), generator=g) for l in range(4)]
+    full, face, lip = masks(), masks(), masks()
+    ms, t = [1.0, 0.7, 1.3], torch.tensor(959)
+    with torch.no_grad():
+        # the reference stores the bank in fp16 whatever the run dtype; the native path does the same
+        banks = [b.clone().to(torch.float16) for b in ob]
+        out_o = o["denoising_unet"](lat, t, enc, banks, audio_embedding=audio, mask_cond_fea=fm, full_mask=full,
+                                    face_mask=face, lip_mask=lip, motion_scale=ms, do_cfg=do_cfg)
+    writer = ReferenceAttentionControl(n["reference_unet"], do_classifier_free_guidance=do_cfg, mode="write", fusion_blocks="full")
+    reader = ReferenceAttentionControl(n["denoising_unet"], do_classifier_free_guidance=do_cfg, mode="read", fusion_blocks="full")
+    reader.update(writer)
+    out_n = n["denoising_unet"](lat, t, enc, audio_embedding=audio, mask_cond_fea=fm, full_mask=full, face_mask=face,
+                                lip_mask=lip, motion_scale=ms).sample
+    reader.clear()
+    writer.clear()
+    assert out_n.shape == out_o.shape
+    # the bank is rounded to fp16 on both sides from values that differ by fp32 reassociation noise: a handful of
+    # elements land on the other side of an fp16 rounding boundary, hence 1e-3 rather than 2e-4
+    assert Hn.rel_l2(out_n, out_o) < 1e-3
+    kinds = {c[0] for c in emu.calls}
+    assert {"gemm", "conv3x3", "attention"} <= kinds
+
+
+def test_conditioners_and_vae(emu, oracle):
+    from oracle import harness as Hn
+    o, n = oracle, _native(oracle)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand((1, 3, 2, 64, 64), generator=g)
+    e = torch.randn((1, 512), generator=g)
+    a = torch.randn((1, 3, 5, 12, 16), generator=g)
+    img = torch.rand((2, 3, 64, 64), generator=g) * 2 - 1
+    z = torch.randn((2, 4, 8, 8), generator=g)
+    with torch.no_grad():
+        for name, inp in (("face_locator", x), ("imageproj", e), ("audioproj", a)):
+            ref, got = o[name](inp), n[name](inp)
+            assert got.shape == ref.shape and Hn.rel_l2(got, ref) < TOL, name
+        assert Hn.rel_l2(n["vae"].encode(img).latent_dist.mean, o["vae"].encode(img).latent_dist.mean) < TOL
+        assert Hn.rel_l2(n["vae"].decode(z).sample, o["vae"].decode(z).sample) < TOL
+
+
+@pytest.mark.parametrize("guidance", [3.5, 1.0])
+def test_pipeline_end_to_end(emu, oracle, guidance):
+    """FaceAnimatePipeline.__call__ vs oracle.hallo_ref.animate: 64x64, 2 frames, 2 DDIM steps, per-step latents, schedule
+    indices and decoded frames."""
+    from oracle import harness as Hn
+    from oracle import hallo_ref as H
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.scheduler import DDIMScheduler
+    o, n = oracle, _native(oracle)
+    S, Fr, steps = 64, 2, 2
+    d = Hn.clip_inputs(S, Fr)
+    args = (d["ref_image"], d["face_emb"], d["audio"], d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr, steps, guidance)
+    seen_o, seen_n = [], []
+    with torch.no_grad():
+        vid_o = H.animate(o["vae"], o["reference_unet"], o["denoising_unet"], o["face_locator"], o["imageproj"],
+                          H.make_scheduler(), *args, motion_scale=d["motion_scale"], latents=d["latents"],
+                          callback=lambda i, t, l: seen_o.append((int(t), l.clone())))
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched)
+    vid_n = pipe(*args, motion_scale=d["motion_scale"], latents=d["latents"],
+                 callback=lambda i, t, l: seen_n.append((int(t), l.float().clone()))).videos
+    assert [t for t, _ in seen_n] == [t for t, _ in seen_o] == [999, 499]
+    assert max(Hn.rel_l2(a, b) for (_, a), (_, b) in zip(seen_n, seen_o)) < 1e-3
+    assert vid_n.shape == vid_o.shape == (1, 3, Fr, S, S) and vid_n.dtype == torch.float32
+    assert Hn.psnr(vid_n, vid_o) > 60.0
+
+
+def test_sliding_window_driver(emu, oracle):
+    """hallo_amd.animate.video.generate_video (motion-frame carry, audio windowing, one generator stream for all clips,
+    trim to the audio length) vs the oracle driver around the oracle pipeline: 3 clips of 2 frames."""
+    from oracle import harness as Hn
+    from oracle import hallo_ref as H
+    from oracle import driver_ref as D
+    from hallo_amd.animate import video as V
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline, FaceAnimatePipelineOutput
+    from hallo_amd.scheduler import DDIMScheduler
+    o, n = oracle, _native(oracle)
+    S, Fr, steps, gs, T = 64, 2, 1, 3.5, 7
+    g = torch.Generator().manual_seed(77)
+    src = torch.rand((3, S, S), generator=g) * 2 - 1
+    region = torch.zeros((3, S, S))
+    region[:, S // 4: 3 * S // 4, S // 4: 3 * S // 4] = 1.0
+    emb = torch.randn((512,), generator=g)
+    lat = S // 8
+    mk = lambda: [torch.rand((1, (lat // 2 ** l) ** 2), generator=g) for l in range(4)]
+    fm, cm, lm = mk(), mk(), mk()
+    audio = torch.randn((T, 12, 16), generator=g)
+    ms = [1.0, 0.8, 1.2]
+
+    def oracle_call(**kw):
+        lt = torch.randn((1, 4, kw["video_length"], kw["height"] // 8, kw["width"] // 8), generator=kw["generator"])
+        v = H.animate(o["vae"], o["reference_unet"], o["denoising_unet"], o["face_locator"], o["imageproj"],
+                      H.make_scheduler(), kw["ref_image"], kw["face_emb"], kw["audio_tensor"], kw["face_mask"],
+                      kw["pixel_values_full_mask"], kw["pixel_values_face_mask"], kw["pixel_values_lip_mask"], kw["width"],
+                      kw["height"], kw["video_length"], kw["num_inference_steps"], kw["guidance_scale"],
+                      motion_scale=kw["motion_scale"], latents=lt)
+        return FaceAnimatePipelineOutput(videos=v)
+    with torch.no_grad():
+        vo = D.generate_video(oracle_call, lambda a: o["audioproj"](a), src, region, emb, fm, cm, lm, audio, Fr, 2, (S, S),
+                              steps, gs, ms, audio_length=5)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched)
+    vn = V.generate_video(pipe, n["audioproj"], src, region, emb, fm, cm, lm, audio, clip_length=Fr, n_motion_frames=2,
+                          img_size=(S, S), inference_steps=steps, cfg_scale=gs, motion_scale=ms, audio_length=5)
+    assert vn.shape == vo.shape == (3, 5, S, S)
+    for c in range(3):          # later clips inherit the earlier ones' (tiny) differences through the motion frames
+        assert Hn.psnr(vn[:, 2 * c: 2 * c + 2], vo[:, 2 * c: 2 * c + 2]) > 55.0, c

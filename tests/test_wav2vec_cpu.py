@@ -78,21 +78,13 @@ def test_oracle_matches_reference_class(cfg_name, n, seq_len):
 @pytest.fixture()
 def emu(monkeypatch):
     import emu_ops
-    from hallo_amd.models import layers, wav2vec
-    monkeypatch.setattr(wav2vec, "ops", emu_ops)
-    monkeypatch.setattr(layers, "ops", emu_ops)
-    emu_ops.calls.clear()
-    return emu_ops
+    return emu_ops.install(monkeypatch)
 
 
 def _native(cfg, sd):
     from hallo_amd.models.wav2vec import Wav2VecModel
     m = Wav2VecModel(cfg)
     m.load_state_dict(sd, strict=True)
-    for mod in m.modules():                 # what HalloModule.prepare() does, minus its GPU / dtype gate
-        if hasattr(mod, "_prepare"):
-            mod._prepare()
-    m._prepared = True
     return m
 
 
