@@ -51,11 +51,13 @@ SPLITK_WS_BYTES = 128 << 20
 
 
 def _workspace(device):
-    """fp32 scratch for split-K partial sums: one fixed buffer per device (fixed address => hipGraph-safe)."""
-    ws = _splitk_ws.get(device)
+    """fp32 scratch for split-K partial sums: one fixed buffer per (device, stream) -- a fixed address keeps captured
+    launches replayable, and two streams never share partial sums."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _splitk_ws.get(key)
     if ws is None:
         ws = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
-        _splitk_ws[device] = ws
+        _splitk_ws[key] = ws
     return ws
 
 
