@@ -61,7 +61,13 @@ def load_unet3d_pretrained_2d(cls, pretrained_model_path, motion_module_path, su
     if use_landmark:
         unet_config["in_channels"] = 8
         unet_config["out_channels"] = 8
-    model = cls.from_config(unet_config, **(unet_additional_kwargs or {}))
+    # the reference constructor's own defaults (unet_3d.py:159,168) apply to whatever unet_additional_kwargs leaves out:
+    # inference passes both flags True (configs/inference/default.yaml:46-74), stage 1 passes use_motion_module False and
+    # nothing about audio (scripts/train_stage1.py:362-371)
+    kw = dict(unet_additional_kwargs or {})
+    kw.setdefault("use_motion_module", False)
+    kw.setdefault("use_audio_module", False)
+    model = cls.from_config(unet_config, **kw)
     state_dict = dict(_read_weights(model_dir))
 
     mm_path = str(motion_module_path) if motion_module_path is not None else ""

@@ -63,14 +63,17 @@ class UNet3DConditionModel(HalloModule):
         super().__init__()
         if (tuple(down_block_types) != ("CrossAttnDownBlock3D",) * 3 + ("DownBlock3D",)
                 or tuple(up_block_types) != ("UpBlock3D",) + ("CrossAttnUpBlock3D",) * 3
-                or not (use_motion_module and use_audio_module and motion_module_mid_block)
+                or use_motion_module != use_audio_module or (use_motion_module and not motion_module_mid_block)
                 or motion_module_decoder_only or act_fn != "silu" or center_input_sample):
-            raise ValueError("hallo_amd builds the Hallo inference configuration of UNet3DConditionModel "
-                             "(configs/inference/default.yaml:46-74 on the SD-1.5 block layout) only")
+            raise ValueError("hallo_amd builds two configurations of UNet3DConditionModel on the SD-1.5 block layout: the "
+                             "Hallo inference one (configs/inference/default.yaml:46-74: motion + audio modules) and the "
+                             "stage-1 one (scripts/train_stage1.py:362-371: neither)")
         mm = dict(DEFAULT_MOTION_MODULE_KWARGS)
         if motion_module_kwargs:
             mm.update(motion_module_kwargs)
         mm["attention_block_types"] = tuple(mm["attention_block_types"])
+        if not use_motion_module:
+            mm = None                      # stage 1: the blocks carry None in place of audio / motion modules
         boc = tuple(block_out_channels)
         heads = attention_head_dim
         ted = boc[0] * 4
@@ -220,13 +223,15 @@ class UNet3DConditionModel(HalloModule):
         x = sample.to(dev).permute(0, 2, 1, 3, 4).reshape(n, Cin, L).contiguous()
         x = ops.nchw_to_nhwc(x.float(), n, Cin, L, self.conv_in.cin_pad, dt)
         enc = encoder_hidden_states.to(dev, dt)
-        audio = audio_embedding.to(dev, dt).reshape(n, audio_embedding.shape[-2], audio_embedding.shape[-1])
+        audio = None
+        if audio_embedding is not None:
+            audio = audio_embedding.to(dev, dt).reshape(n, audio_embedding.shape[-2], audio_embedding.shape[-1])
         mc = None
         if mask_cond_fea is not None:
             C0 = mask_cond_fea.shape[1]
             mc = mask_cond_fea.to(dev).permute(0, 2, 1, 3, 4).reshape(n, C0, L).contiguous()
             mc = ops.nchw_to_nhwc(mc.float(), n, C0, L, C0, dt)
-        masks = pack_masks(full_mask, face_mask, lip_mask, dev, dt)
+        masks = pack_masks(full_mask, face_mask, lip_mask, dev, dt) if full_mask is not None else None
         y = self.forward_tokens(x, timestep, enc, self.reference_bank, audio, mc, masks, motion_scale, B, F, H, W,
                                 self.reference_do_cfg, cache if cache is not None else NO_CACHE)
         Co = y.shape[-1]

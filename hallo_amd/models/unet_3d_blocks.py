@@ -11,6 +11,10 @@ after it (unet_3d_blocks.py:696-748, 1148-1202), (b) motion_scale reaches every 
 (c) DownBlock3D / UpBlock3D skip their motion modules entirely (:905-915, :1376-1386) although they
 own the parameters.  `block_semantics="eval"` is not implemented: nothing in the reference's
 inference path reaches it.
+
+`mm_kwargs=None` builds the stage-1 configuration (scripts/train_stage1.py:362-371: use_motion_module=False, no audio
+modules): the audio / motion entries of every block are None, exactly as in the reference's ModuleLists, and a layer is
+resnet -> spatial transformer (the reference's training and eval branches coincide there, unet_3d_blocks.py:681-765).
 """
 import torch
 from torch import nn
@@ -63,6 +67,8 @@ def _layer(st, x, H, W, attn, audio, motion, depth):
     n, L, Cd = x.shape
     bank = st.next_bank()
     x = attn.run_spatial(x, st.enc, bank, F, st.do_cfg, st.cache)
+    if audio is None and motion is None:        # stage-1 configuration
+        return x
 
     # motion-frame features = bank[:, 1:] (mutual_self_attention.py:327), cast once per clip
     def mf_make():
@@ -100,6 +106,10 @@ class CrossAttnDownBlock3D(nn.Module):
             attentions.append(Transformer3DModel(heads, out_channels // heads, out_channels, cross_attention_dim, groups))
             # unet_3d_blocks.py:585-605: the audio transformer's head dim comes from the layer's INPUT width
             # ("# TODO:检查维度" in the reference), so several audio transformers run at half width
+            if mm_kwargs is None:
+                audio_modules.append(None)
+                motion_modules.append(None)
+                continue
             audio_modules.append(Transformer3DModel(heads, in_ch // heads, out_channels, audio_attention_dim, groups,
                                                     use_audio_module=True, depth=depth))
             motion_modules.append(VanillaTemporalModule(out_channels, norm_num_groups=groups, **mm_kwargs))
@@ -127,7 +137,8 @@ class DownBlock3D(nn.Module):
         self.resnets = nn.ModuleList([ResnetBlock3D(in_channels if i == 0 else out_channels, out_channels,
                                                     temb_channels, eps, groups) for i in range(num_layers)])
         # parameters exist in the checkpoint; never executed as shipped (F2c)
-        self.motion_modules = nn.ModuleList([VanillaTemporalModule(out_channels, norm_num_groups=groups, **mm_kwargs)
+        self.motion_modules = nn.ModuleList([None if mm_kwargs is None else
+                                             VanillaTemporalModule(out_channels, norm_num_groups=groups, **mm_kwargs)
                                              for _ in range(num_layers)])
         self.downsamplers = None
 
@@ -147,6 +158,9 @@ class UNetMidBlock3DCrossAttn(nn.Module):
                                                             cross_attention_dim, groups)])
         self.resnets = nn.ModuleList([ResnetBlock3D(in_channels, in_channels, temb_channels, eps, groups),
                                       ResnetBlock3D(in_channels, in_channels, temb_channels, eps, groups)])
+        if mm_kwargs is None:
+            self.audio_modules, self.motion_modules = nn.ModuleList([None]), nn.ModuleList([None])
+            return
         self.audio_modules = nn.ModuleList([Transformer3DModel(heads, in_channels // heads, in_channels,
                                                                audio_attention_dim, groups, use_audio_module=True,
                                                                depth=3)])
@@ -169,6 +183,10 @@ class CrossAttnUpBlock3D(nn.Module):
             resnet_in = prev_output_channel if i == 0 else out_channels
             resnets.append(ResnetBlock3D(resnet_in + res_skip, out_channels, temb_channels, eps, groups))
             attentions.append(Transformer3DModel(heads, out_channels // heads, out_channels, cross_attention_dim, groups))
+            if mm_kwargs is None:
+                audio_modules.append(None)
+                motion_modules.append(None)
+                continue
             audio_modules.append(Transformer3DModel(heads, in_channels // heads, out_channels, audio_attention_dim,
                                                     groups, use_audio_module=True, depth=depth))
             motion_modules.append(VanillaTemporalModule(out_channels, norm_num_groups=groups, **mm_kwargs))
@@ -199,7 +217,8 @@ class UpBlock3D(nn.Module):
             resnet_in = prev_output_channel if i == 0 else out_channels
             resnets.append(ResnetBlock3D(resnet_in + res_skip, out_channels, temb_channels, eps, groups))
         self.resnets = nn.ModuleList(resnets)
-        self.motion_modules = nn.ModuleList([VanillaTemporalModule(out_channels, norm_num_groups=groups, **mm_kwargs)
+        self.motion_modules = nn.ModuleList([None if mm_kwargs is None else
+                                             VanillaTemporalModule(out_channels, norm_num_groups=groups, **mm_kwargs)
                                              for _ in range(num_layers)])
         self.upsamplers = nn.ModuleList([Upsample3D(out_channels, out_channels)]) if add_upsample else None
 

@@ -179,7 +179,9 @@ def is_xformers_available():
 
 
 def is_accelerate_available():
-    return False
+    # face_animate_static.py:58-61 refuses to import without accelerate (it only uses cpu_offload, never called here)
+    import importlib.util
+    return importlib.util.find_spec("accelerate") is not None
 
 
 def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):

@@ -430,6 +430,10 @@ class CrossAttnDownBlock3D(nn.Module):
             in_ch = in_channels if i == 0 else out_channels
             resnets.append(ResnetBlock3D(in_ch, out_channels, temb_channels, eps, groups))
             attentions.append(Transformer3DModel(heads, out_channels // heads, out_channels, cross_attention_dim, groups))
+            if mm_kwargs is None:       # stage-1 configuration (use_motion_module / use_audio_module False): None entries
+                audio_modules.append(None)
+                motion_modules.append(None)
+                continue
             # unet_3d_blocks.py:585-605: head dim from the *input* width of the layer (F7)
             audio_modules.append(Transformer3DModel(heads, in_ch // heads, out_channels, audio_attention_dim, groups,
                                                     use_audio_module=True, depth=depth))
@@ -445,9 +449,12 @@ class CrossAttnDownBlock3D(nn.Module):
         for resnet, attn, audio, motion in zip(self.resnets, self.attentions, self.audio_modules, self.motion_modules):
             hidden_states = resnet(hidden_states, temb)
             hidden_states, mf = attn(hidden_states, enc, bank=banks.pop(0), do_cfg=ctx["do_cfg"])
-            hidden_states, _ = audio(hidden_states, ctx["audio"], full_mask=ctx["full_mask"], face_mask=ctx["face_mask"],
-                                     lip_mask=ctx["lip_mask"], motion_scale=ctx["motion_scale"])
-            hidden_states = _motion_concat(hidden_states, mf, motion)
+            if audio is not None:
+                hidden_states, _ = audio(hidden_states, ctx["audio"], full_mask=ctx["full_mask"],
+                                         face_mask=ctx["face_mask"], lip_mask=ctx["lip_mask"],
+                                         motion_scale=ctx["motion_scale"])
+            if motion is not None:
+                hidden_states = _motion_concat(hidden_states, mf, motion)
             output_states += (hidden_states,)
         if self.downsamplers is not None:
             hidden_states = self.downsamplers[0](hidden_states)
@@ -463,7 +470,8 @@ class DownBlock3D(nn.Module):
         super().__init__()
         self.resnets = nn.ModuleList([ResnetBlock3D(in_channels if i == 0 else out_channels, out_channels,
                                                     temb_channels, eps, groups) for i in range(num_layers)])
-        self.motion_modules = nn.ModuleList([VanillaTemporalModule(out_channels, norm_num_groups=groups, **mm_kwargs)
+        self.motion_modules = nn.ModuleList([None if mm_kwargs is None else
+                                             VanillaTemporalModule(out_channels, norm_num_groups=groups, **mm_kwargs)
                                              for _ in range(num_layers)])
         self.downsamplers = None
 
@@ -485,6 +493,9 @@ class UNetMidBlock3DCrossAttn(nn.Module):
                                                             cross_attention_dim, groups)])
         self.resnets = nn.ModuleList([ResnetBlock3D(in_channels, in_channels, temb_channels, eps, groups),
                                       ResnetBlock3D(in_channels, in_channels, temb_channels, eps, groups)])
+        if mm_kwargs is None:
+            self.audio_modules, self.motion_modules = nn.ModuleList([None]), nn.ModuleList([None])
+            return
         self.audio_modules = nn.ModuleList([Transformer3DModel(heads, in_channels // heads, in_channels,
                                                                audio_attention_dim, groups, use_audio_module=True,
                                                                depth=3)])
@@ -493,10 +504,12 @@ class UNetMidBlock3DCrossAttn(nn.Module):
     def forward(self, hidden_states, temb, enc, banks, ctx):
         hidden_states = self.resnets[0](hidden_states, temb)
         hidden_states, mf = self.attentions[0](hidden_states, enc, bank=banks.pop(0), do_cfg=ctx["do_cfg"])
-        hidden_states, _ = self.audio_modules[0](hidden_states, ctx["audio"], full_mask=ctx["full_mask"],
-                                                 face_mask=ctx["face_mask"], lip_mask=ctx["lip_mask"],
-                                                 motion_scale=ctx["motion_scale"])
-        hidden_states = _motion_concat(hidden_states, mf, self.motion_modules[0])
+        if self.audio_modules[0] is not None:
+            hidden_states, _ = self.audio_modules[0](hidden_states, ctx["audio"], full_mask=ctx["full_mask"],
+                                                     face_mask=ctx["face_mask"], lip_mask=ctx["lip_mask"],
+                                                     motion_scale=ctx["motion_scale"])
+        if self.motion_modules[0] is not None:
+            hidden_states = _motion_concat(hidden_states, mf, self.motion_modules[0])
         return self.resnets[1](hidden_states, temb)
 
 
@@ -512,6 +525,10 @@ class CrossAttnUpBlock3D(nn.Module):
             resnet_in = prev_output_channel if i == 0 else out_channels
             resnets.append(ResnetBlock3D(resnet_in + res_skip, out_channels, temb_channels, eps, groups))
             attentions.append(Transformer3DModel(heads, out_channels // heads, out_channels, cross_attention_dim, groups))
+            if mm_kwargs is None:
+                audio_modules.append(None)
+                motion_modules.append(None)
+                continue
             audio_modules.append(Transformer3DModel(heads, in_channels // heads, out_channels, audio_attention_dim,
                                                     groups, use_audio_module=True, depth=depth))
             motion_modules.append(VanillaTemporalModule(out_channels, norm_num_groups=groups, **mm_kwargs))
@@ -528,9 +545,12 @@ class CrossAttnUpBlock3D(nn.Module):
             hidden_states = torch.cat([hidden_states, res], dim=1)
             hidden_states = resnet(hidden_states, temb)
             hidden_states, mf = attn(hidden_states, enc, bank=banks.pop(0), do_cfg=ctx["do_cfg"])
-            hidden_states, _ = audio(hidden_states, ctx["audio"], full_mask=ctx["full_mask"], face_mask=ctx["face_mask"],
-                                     lip_mask=ctx["lip_mask"], motion_scale=ctx["motion_scale"])
-            hidden_states = _motion_concat(hidden_states, mf, motion)
+            if audio is not None:
+                hidden_states, _ = audio(hidden_states, ctx["audio"], full_mask=ctx["full_mask"],
+                                         face_mask=ctx["face_mask"], lip_mask=ctx["lip_mask"],
+                                         motion_scale=ctx["motion_scale"])
+            if motion is not None:
+                hidden_states = _motion_concat(hidden_states, mf, motion)
         if self.upsamplers is not None:
             hidden_states = self.upsamplers[0](hidden_states)
         return hidden_states
@@ -548,7 +568,8 @@ class UpBlock3D(nn.Module):
             resnet_in = prev_output_channel if i == 0 else out_channels
             resnets.append(ResnetBlock3D(resnet_in + res_skip, out_channels, temb_channels, eps, groups))
         self.resnets = nn.ModuleList(resnets)
-        self.motion_modules = nn.ModuleList([VanillaTemporalModule(out_channels, norm_num_groups=groups, **mm_kwargs)
+        self.motion_modules = nn.ModuleList([None if mm_kwargs is None else
+                                             VanillaTemporalModule(out_channels, norm_num_groups=groups, **mm_kwargs)
                                              for _ in range(num_layers)])
         self.upsamplers = nn.ModuleList([Upsample3D(out_channels, out_channels)]) if add_upsample else None
 
@@ -566,15 +587,22 @@ class UpBlock3D(nn.Module):
 # =============================================================================== unet_3d.py
 class UNet3DConditionModel(nn.Module):
     """hallo/models/unet_3d.py:59-715 in the inference configuration of
-    configs/inference/default.yaml:46-74 on the SD-1.5 UNet config."""
+    configs/inference/default.yaml:46-74 on the SD-1.5 UNet config, or -- use_motion_module = use_audio_module = False --
+    the stage-1 configuration of scripts/train_stage1.py:362-371 (no audio / motion modules: with both absent the
+    training and the eval branch of every block compute the same thing, unet_3d_blocks.py:681-765)."""
 
     def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
                  norm_num_groups=32, norm_eps=1e-5, cross_attention_dim=768, attention_head_dim=8,
-                 audio_attention_dim=768, motion_module_kwargs=None, flip_sin_to_cos=True, freq_shift=0):
+                 audio_attention_dim=768, motion_module_kwargs=None, flip_sin_to_cos=True, freq_shift=0,
+                 use_motion_module=True, use_audio_module=True):
         super().__init__()
+        if use_motion_module != use_audio_module:
+            raise ValueError("restated configurations: inference (both modules) and stage 1 (neither)")
         mm = dict(HALLO_UNET_KWARGS["motion_module_kwargs"])
         if motion_module_kwargs:
             mm.update(motion_module_kwargs)
+        if not use_motion_module:
+            mm = None
         heads = attention_head_dim
         boc = tuple(block_out_channels)
         time_embed_dim = boc[0] * 4
@@ -954,6 +982,46 @@ def animate(vae, reference_unet, denoising_unet, face_locator, image_proj, sched
             callback(i, t, latents)
     if not decode:
         return latents
+    return decode_latents(vae, latents)
+
+
+@torch.no_grad()
+def animate_static(vae, reference_unet, denoising_unet, face_locator, image_proj, scheduler, ref_image, face_mask, width,
+                   height, num_inference_steps, guidance_scale, face_embedding, generator=None, latents=None,
+                   callback=None, bank_dtype=torch.float16):
+    """hallo/animate/face_animate_static.py:312-481 (StaticPipeline.__call__, the stage-1 single-image pipeline) on
+    already-preprocessed tensors: ref_image (b, 3, H, W) in [-1, 1], face_mask (b, 3, H, W) in [0, 1] (what the two
+    VaeImageProcessor.preprocess calls return, :390-405).  Differences from `animate` that are the reference's own:
+    one reference image, no audio, F = 1, and the face-locator feature is given to BOTH CFG halves (:407-411)."""
+    do_cfg = guidance_scale > 1.0
+    scheduler.set_timesteps(num_inference_steps)
+    timesteps = scheduler.timesteps
+    dtype = next(denoising_unet.parameters()).dtype
+    enc = image_proj(face_embedding.to(dtype))
+    uncond = image_proj(torch.zeros_like(face_embedding.to(dtype)))
+    if do_cfg:
+        enc = torch.cat([uncond, enc], dim=0)
+    if latents is None:
+        shape = (1, 4, height // 8, width // 8)
+        latents = randn_tensor(shape, generator=generator, device=torch.device("cpu"), dtype=face_embedding.dtype)
+    latents = (latents * scheduler.init_noise_sigma).unsqueeze(2)
+    ref_latents = vae.encode(ref_image.to(dtype)).latent_dist.mean * 0.18215
+    fm = face_locator(face_mask.unsqueeze(2).to(dtype))
+    if do_cfg:
+        fm = torch.cat([fm] * 2)
+    banks = None
+    for i, t in enumerate(timesteps):
+        if i == 0:
+            banks = reference_unet(ref_latents.repeat(2 if do_cfg else 1, 1, 1, 1), torch.zeros_like(t), enc)
+            banks = [b.clone().to(bank_dtype) for b in banks]
+        x_in = torch.cat([latents] * 2) if do_cfg else latents
+        noise_pred = denoising_unet(x_in, t, enc, banks, mask_cond_fea=fm, do_cfg=do_cfg)
+        if do_cfg:
+            nu, nc = noise_pred.chunk(2)
+            noise_pred = nu + guidance_scale * (nc - nu)
+        latents = scheduler.step(noise_pred, t, latents, eta=0.0, return_dict=False)[0]
+        if callback is not None:
+            callback(i, t, latents)
     return decode_latents(vae, latents)
 
 

@@ -74,6 +74,22 @@ def native_nets(oracle, cfg=SMALL, audio_dim=SMALL_AUDIO_DIM, vae_cfg=SMALL_VAE,
     return nets
 
 
+def stage1_nets(oracle, dtype=torch.float16, device="cuda:0", cfg=SMALL, seed=40):
+    """(oracle, native) stage-1 denoising UNets (scripts/train_stage1.py:362-371: no motion / audio modules) on identical
+    synthetic weights; the other nets of `oracle` / `native_nets(oracle)` are shared with the clip pipeline."""
+    from hallo_amd.models.unet_3d import UNet3DConditionModel
+    o = H.UNet3DConditionModel(use_motion_module=False, use_audio_module=False, **cfg)
+    H.fill_synthetic_(o, seed, zero_init_std=ZERO_INIT_STD)
+    o.load_state_dict(round_to(o.state_dict(), dtype))
+    o.eval()
+    n = UNet3DConditionModel(use_motion_module=False, use_audio_module=False, **cfg)
+    missing, unexpected = n.load_state_dict(o.state_dict(), strict=True)
+    assert not missing and not unexpected
+    n.to(device=device, dtype=dtype)
+    n.prepare()
+    return o, n
+
+
 def clip_inputs(size, frames, audio_dim=SMALL_AUDIO_DIM, seed=1234):
     """Synthetic per-clip inputs, audio already projected to (1, F, 32, audio_dim)."""
     g = torch.Generator().manual_seed(seed)

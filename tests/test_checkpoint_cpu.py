@@ -98,6 +98,29 @@ def test_from_pretrained_2d_matches_reference_loader(tmp_path, fmt, mm_suffix, z
         assert all(("proj_out" in k) or ("motion_modules" not in k) for k in fresh if "motion_modules" in k or "proj_out" in k)
 
 
+def test_from_pretrained_2d_stage1_matches_reference_loader(tmp_path):
+    """scripts/train_stage1.py:362-371: from_pretrained_2d(base, "", subfolder="unet", unet_additional_kwargs={
+    "use_motion_module": False, "unet_use_temporal_attention": False}, use_landmark=False) -- the stage-1 UNet that
+    StaticPipeline denoises with: no motion / audio modules, every parameter comes from the SD-1.5 file."""
+    if not R.reference_available():
+        pytest.skip("needs /root/reference (authoring container)")
+    tmp = str(tmp_path)
+    sd2d = _sd15_like_checkpoint(tmp, "safetensors")
+    kw = {"use_motion_module": False, "unet_use_temporal_attention": False}
+    from hallo_amd.models.unet_3d import UNet3DConditionModel as Native
+    n = Native.from_pretrained_2d(tmp, "", subfolder="unet", unet_additional_kwargs=dict(kw), use_landmark=False)
+    R.enable()
+    from hallo.models.unet_3d import UNet3DConditionModel as Ref
+    r = Ref.from_pretrained_2d(tmp, "", subfolder="unet", unet_additional_kwargs=dict(kw), use_landmark=False)
+    nsd, rsd = n.state_dict(), r.state_dict()
+    assert set(nsd) == set(rsd) and len(nsd) == 686 and not any("motion" in k or "audio" in k for k in nsd)
+    # the synthetic SD-1.5-like file (written from a ReferenceNet) has no conv_out: those two keep their fresh init
+    assert set(nsd) - set(sd2d) == {"conv_out.weight", "conv_out.bias"} == set(n.loading_info["missing_keys"])
+    for k in set(nsd) & set(sd2d):
+        assert torch.equal(nsd[k], rsd[k]) and torch.equal(nsd[k], sd2d[k]), k
+    assert n.loading_info["unexpected_keys"] == []
+
+
 def test_from_pretrained_2d_landmark_and_shape_rule(tmp_path):
     """use_landmark=True builds an 8-channel conv_in/conv_out; the 4-channel checkpoint tensors do not fit and are
     replaced by the fresh initialisation (unet_3d.py:826-830), everything else loads."""

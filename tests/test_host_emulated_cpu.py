@@ -161,3 +161,56 @@ def test_sliding_window_driver(emu, oracle):
     assert vn.shape == vo.shape == (3, 5, S, S)
     for c in range(3):          # later clips inherit the earlier ones' (tiny) differences through the motion frames
         assert Hn.psnr(vn[:, 2 * c: 2 * c + 2], vo[:, 2 * c: 2 * c + 2]) > 55.0, c
+
+
+@pytest.mark.parametrize("guidance", [3.5, 1.0])
+def test_static_pipeline(emu, oracle, guidance):
+    """Stage-1 StaticPipeline (F = 1, one reference image, no audio / motion modules) vs oracle.hallo_ref.animate_static,
+    which tests/test_oracle_vs_reference.py pins bit-exact against the reference's own StaticPipeline."""
+    from oracle import harness as Hn
+    from oracle import hallo_ref as H
+    from hallo_amd.animate.face_animate_static import StaticPipeline
+    from hallo_amd.scheduler import DDIMScheduler
+    o, n = oracle, _native(oracle)
+    oden, nden = Hn.stage1_nets(o, dtype=torch.float32, device="cpu")
+    assert len(nden.state_dict()) == len(oden.state_dict()) and not any("motion" in k or "audio" in k for k in nden.state_dict())
+    S, steps = 64, 2
+    g = torch.Generator().manual_seed(21)
+    ref_image = torch.rand((1, 3, S, S), generator=g) * 2 - 1
+    face_mask = (torch.rand((1, 3, S, S), generator=g) > 0.5).float()
+    emb = torch.randn((1, 512), generator=g)
+    seen_o, seen_n = [], []
+    with torch.no_grad():
+        img_o = H.animate_static(o["vae"], o["reference_unet"], oden, o["face_locator"], o["imageproj"], H.make_scheduler(),
+                                 ref_image, face_mask, S, S, steps, guidance, emb, generator=torch.Generator().manual_seed(4),
+                                 callback=lambda i, t, l: seen_o.append((int(t), l.clone())))
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    pipe = StaticPipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=nden,
+                          face_locator=n["face_locator"], imageproj=n["imageproj"], scheduler=sched)
+    img_n = pipe(ref_image, face_mask, S, S, steps, guidance, emb, generator=torch.Generator().manual_seed(4),
+                 callback=lambda i, t, l: seen_n.append((int(t), l.float().clone()))).images
+    assert [t for t, _ in seen_n] == [t for t, _ in seen_o] == [999, 499]
+    assert max(Hn.rel_l2(a, b) for (_, a), (_, b) in zip(seen_n, seen_o)) < 1e-3
+    assert img_n.shape == img_o.shape == (1, 3, 1, S, S) and img_n.dtype == torch.float32
+    assert Hn.psnr(img_n, img_o) > 60.0
+
+
+def test_static_pipeline_pil_inputs():
+    """PIL -> tensor conversion of the two image processors (RGB, lanczos resize, /255, 2x - 1 for the reference image)."""
+    import numpy as np
+    from PIL import Image
+    from hallo_amd.animate.face_animate_static import preprocess_image
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, 256, size=(32, 32, 3), dtype=np.uint8)
+    im = Image.fromarray(arr)
+    x = preprocess_image(im, 32, 32, normalize=True)
+    assert x.shape == (1, 3, 32, 32) and torch.equal(x, torch.from_numpy(arr).permute(2, 0, 1)[None].float() / 255.0 * 2 - 1)
+    m = preprocess_image(Image.fromarray(arr[..., 0]), 32, 32, normalize=False)          # grayscale mask -> RGB, [0, 1]
+    assert m.shape == (1, 3, 32, 32) and float(m.min()) >= 0.0 and torch.equal(m[0, 0], m[0, 2])
+    assert preprocess_image(im, 16, 16, normalize=False).shape == (1, 3, 16, 16)       # resized to (width, height)
+    t = torch.rand((1, 3, 8, 8))
+    assert torch.equal(preprocess_image(t, 8, 8, normalize=True), 2 * t - 1)             # in [0, 1]: normalised
+    assert torch.equal(preprocess_image(t - 0.5, 8, 8, normalize=True), t - 0.5)         # already signed: kept
+    with pytest.raises(ValueError):
+        preprocess_image(t, 16, 16, normalize=False)

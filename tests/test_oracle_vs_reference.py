@@ -133,3 +133,55 @@ def test_pipeline_bit_exact_cfg(nets):
     for (_, a), (_, b) in zip(seen_r, seen_o):
         assert torch.equal(a, b)
     assert out_r.shape == (1, 3, Fr, S, S) and torch.equal(out_r, out_o)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# stage-1 StaticPipeline: hallo/animate/face_animate_static.py:312-481 with the stage-1 UNet of
+# scripts/train_stage1.py:362-371 (use_motion_module=False, no audio modules)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("guidance", [3.5, 1.0])
+def test_static_pipeline_bit_exact(guidance):
+    from oracle import hallo_ref as H
+    R.enable()
+    from diffusers import AutoencoderKL
+    from hallo.animate.face_animate_static import StaticPipeline
+    from hallo.models.face_locator import FaceLocator
+    from hallo.models.image_proj import ImageProjModel
+    from hallo.models.unet_2d_condition import UNet2DConditionModel
+    from hallo.models.unet_3d import UNet3DConditionModel
+    cfg = R.tiny_cfg(32, 64)
+    c3 = dict(cfg)
+    c3["down_block_types"] = ["CrossAttnDownBlock3D"] * 3 + ["DownBlock3D"]
+    c3["up_block_types"] = ["UpBlock3D"] + ["CrossAttnUpBlock3D"] * 3
+    c3["mid_block_type"] = "UNetMidBlock3DCrossAttn"
+    rden = UNet3DConditionModel.from_config(c3, use_motion_module=False, unet_use_temporal_attention=False)
+    rref = UNet2DConditionModel.from_config(dict(cfg)).eval()
+    keys = ("in_channels", "out_channels", "block_out_channels", "layers_per_block", "norm_num_groups", "norm_eps",
+            "cross_attention_dim", "attention_head_dim")
+    oden = H.UNet3DConditionModel(use_motion_module=False, use_audio_module=False, **{k: cfg[k] for k in keys})
+    oref = H.UNet2DConditionModel(**{k: cfg[k] for k in keys if k != "out_channels"})
+    assert {k: v.shape for k, v in rden.state_dict().items()} == {k: v.shape for k, v in oden.state_dict().items()}
+    assert len(rden.state_dict()) == 686 and not any("motion" in k or "audio" in k for k in rden.state_dict())
+    vae = AutoencoderKL(block_out_channels=(32, 32, 64, 64), norm_num_groups=32)
+    r_fl, o_fl = FaceLocator(conditioning_embedding_channels=32), H.FaceLocator(32)
+    r_ip = ImageProjModel(cross_attention_dim=64, clip_embeddings_dim=512, clip_extra_context_tokens=4)
+    o_ip = H.ImageProjModel(64, 512, 4)
+    for m, s in ((rden, 1), (oden, 1), (rref, 2), (oref, 2), (vae, 7), (r_fl, 8), (o_fl, 8), (r_ip, 9), (o_ip, 9)):
+        H.fill_synthetic_(m, s)
+    S = 64
+    g = torch.Generator().manual_seed(5)
+    ref_image = torch.rand((1, 3, S, S), generator=g) * 2 - 1          # what VaeImageProcessor.preprocess hands over
+    face_mask = (torch.rand((1, 3, S, S), generator=g) > 0.5).float()
+    face_emb = torch.randn((1, 512), generator=g)
+    pipe = StaticPipeline(vae=vae, reference_unet=rref, denoising_unet=rden, face_locator=r_fl, imageproj=r_ip,
+                          scheduler=H.make_scheduler())
+    seen_r, seen_o = [], []
+    out_r = pipe(ref_image, face_mask, S, S, 3, guidance, face_emb, generator=torch.Generator().manual_seed(42),
+                 callback=lambda i, t, l: seen_r.append((int(t), l.clone()))).images
+    out_o = H.animate_static(vae, oref, oden, o_fl, o_ip, H.make_scheduler(), ref_image, face_mask, S, S, 3, guidance,
+                             face_emb, generator=torch.Generator().manual_seed(42),
+                             callback=lambda i, t, l: seen_o.append((int(t), l.clone())))
+    assert [t for t, _ in seen_r] == [t for t, _ in seen_o] == [999, 666, 332]
+    for (_, a), (_, b) in zip(seen_r, seen_o):
+        assert torch.equal(a, b)
+    assert out_r.shape == (1, 3, 1, S, S) and torch.equal(out_r, out_o)
