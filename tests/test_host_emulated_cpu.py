@@ -214,3 +214,68 @@ def test_static_pipeline_pil_inputs():
     assert torch.equal(preprocess_image(t - 0.5, 8, 8, normalize=True), t - 0.5)         # already signed: kept
     with pytest.raises(ValueError):
         preprocess_image(t, 16, 16, normalize=False)
+
+
+# wav2vec configuration whose hidden size is the harness AudioProjModel's `channels` (16) with the base model's 12 layers
+W2V_PLUMBING = dict(conv_dim=(32,) * 7, conv_stride=(5, 2, 2, 2, 2, 2, 2), conv_kernel=(10, 3, 3, 3, 3, 2, 2), conv_bias=False,
+                    feat_extract_norm="group", num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=2, hidden_size=16,
+                    num_attention_heads=2, num_hidden_layers=12, intermediate_size=32, layer_norm_eps=1e-5)
+
+
+def test_inference_plumbing_waveform_to_frames(emu, oracle):
+    """The whole chain of scripts/inference.py:166-347 behind the file / face-analysis I/O (BASELINE config #0's
+    "scripts/inference.py plumbing", scaled down): 16 kHz waveform -> AudioProcessor (normalise, pad to clip_length,
+    wav2vec2, 12-layer stack) -> process_audio_emb windows -> AudioProjModel -> sliding-window clips with motion-frame
+    carry -> frames trimmed to the audio length.  Native chain vs oracle chain, both fp32 on the CPU."""
+    from oracle import harness as Hn
+    from oracle import hallo_ref as H
+    from oracle import driver_ref as D
+    from oracle import wav2vec_ref as W
+    from hallo_amd.animate import video as V
+    from hallo_amd.animate.audio import AudioProcessor
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline, FaceAnimatePipelineOutput
+    from hallo_amd.models.wav2vec import Wav2VecModel
+    from hallo_amd.scheduler import DDIMScheduler
+    o, n = oracle, _native(oracle)
+    S, Fr, steps, gs = 64, 2, 1, 3.5
+    sd = W.synthetic_state_dict(W2V_PLUMBING, seed=2)
+    speech = torch.randn(2300, generator=torch.Generator().manual_seed(8)).numpy() * 0.2        # 0.14 s -> 4 frames at 25 fps
+    # ---- oracle chain
+    with torch.no_grad():
+        emb_o, len_o = W.audio_embedding(sd, W2V_PLUMBING, speech, 16000, 25, Fr)
+    # ---- native chain
+    w2v = Wav2VecModel(W2V_PLUMBING)
+    w2v.load_state_dict(sd, strict=True)
+    emb_n, len_n = AudioProcessor(16000, 25, w2v).preprocess_array(speech, clip_length=Fr)
+    assert len_n == len_o == 4 and emb_n.shape == emb_o.shape == (4, 12, 16)
+    assert Hn.rel_l2(emb_n, emb_o) < TOL
+
+    g = torch.Generator().manual_seed(77)
+    src = torch.rand((3, S, S), generator=g) * 2 - 1
+    region = torch.zeros((3, S, S))
+    region[:, S // 4: 3 * S // 4, S // 4: 3 * S // 4] = 1.0
+    face_emb = torch.randn((512,), generator=g)
+    lat = S // 8
+    mk = lambda: [torch.rand((1, (lat // 2 ** l) ** 2), generator=g) for l in range(4)]
+    fm, cm, lm = mk(), mk(), mk()
+    ms = [1.0, 0.8, 1.2]
+
+    def oracle_call(**kw):
+        lt = torch.randn((1, 4, kw["video_length"], kw["height"] // 8, kw["width"] // 8), generator=kw["generator"])
+        v = H.animate(o["vae"], o["reference_unet"], o["denoising_unet"], o["face_locator"], o["imageproj"],
+                      H.make_scheduler(), kw["ref_image"], kw["face_emb"], kw["audio_tensor"], kw["face_mask"],
+                      kw["pixel_values_full_mask"], kw["pixel_values_face_mask"], kw["pixel_values_lip_mask"], kw["width"],
+                      kw["height"], kw["video_length"], kw["num_inference_steps"], kw["guidance_scale"],
+                      motion_scale=kw["motion_scale"], latents=lt)
+        return FaceAnimatePipelineOutput(videos=v)
+    with torch.no_grad():
+        vo = D.generate_video(oracle_call, lambda a: o["audioproj"](a), src, region, face_emb, fm, cm, lm, emb_o, Fr, 2, (S, S),
+                              steps, gs, ms, audio_length=len_o)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched)
+    vn = V.generate_video(pipe, n["audioproj"], src, region, face_emb, fm, cm, lm, emb_n, clip_length=Fr, n_motion_frames=2,
+                          img_size=(S, S), inference_steps=steps, cfg_scale=gs, motion_scale=ms, audio_length=len_n)
+    assert vn.shape == vo.shape == (3, 4, S, S)
+    assert Hn.psnr(vn, vo) > 55.0
