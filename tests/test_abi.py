@@ -71,3 +71,52 @@ def test_cpu_tensors_are_rejected():
     a = torch.zeros(8, 8, dtype=torch.bfloat16)
     with pytest.raises(hl.HalloLibraryError):
         ops.gemm(a, a)
+
+def test_every_entry_point_rejects_bad_arguments(lib):
+    """Error behaviour of the C ABI (include/hallo_amd.h: status -22 = bad argument): every entry point validates its
+    arguments BEFORE touching the device, so this runs without a GPU -- null descriptors / pointers, sizes that break the
+    documented alignment rules, unknown dtype / activation / option names, head dims the kernels are not built for."""
+    import ctypes as C
+    from hallo_amd import lib as L
+    N=None
+    res={}
+    d=L.GemmDesc(); res['gemm_null']=lib.hallo_gemm(None,N); res['gemm_zero']=lib.hallo_gemm(C.byref(d),N)
+    buf=(C.c_char*4096)(); p=C.cast(buf,C.c_void_p)
+    d=L.GemmDesc(); d.A=d.B=d.C=p.value; d.M=8; d.N=8; d.K=12; d.lda=d.ldb=d.ldc=16; d.batch=1
+    res['gemm_K_not_mult8']=lib.hallo_gemm(C.byref(d),N)
+    d.K=16; d.lda=12; res['gemm_lda']=lib.hallo_gemm(C.byref(d),N)
+    d.lda=16; d.act=7; res['gemm_act']=lib.hallo_gemm(C.byref(d),N)
+    d.act=0; d.dtype=5; res['gemm_dtype']=lib.hallo_gemm(C.byref(d),N)
+    c=L.ConvDesc(); res['conv_zero']=lib.hallo_conv3x3_nhwc(C.byref(c),N); res['conv_null']=lib.hallo_conv3x3_nhwc(None,N)
+    a=L.AttnDesc(); res['attn_zero']=lib.hallo_attention(C.byref(a),N); res['attn_null']=lib.hallo_attention(None,N)
+    a=L.AttnDesc(); a.q=a.k1=a.v1=a.o=p.value; a.batch=1; a.heads=2; a.head_dim=64; a.Lq=8; a.Lkv1=8
+    res['attn_hd64']=lib.hallo_attention(C.byref(a),N)
+    res['temporal_null']=lib.hallo_temporal_attention(N,N,1,4,4,80,2,1.0,0,N)
+    res['temporal_F33']=lib.hallo_temporal_attention(p,p,1,33,4,80,2,1.0,0,N)
+    res['gn_null']=lib.hallo_groupnorm_nhwc(N,N,N,N,N,1,4,32,4,1e-5,0,0,N)
+    res['gn_cpg1']=lib.hallo_groupnorm_nhwc(p,p,p,p,p,1,4,32,32,1e-5,0,0,N)
+    res['ln_null']=lib.hallo_layernorm(N,N,N,N,N,4,32,1e-5,1,1,0,N)
+    res['ln_C_not8']=lib.hallo_layernorm(p,p,p,p,N,4,20,1e-5,1,1,0,N)
+    res['softmax_null']=lib.hallo_softmax_rows(N,N,4,8,1.0,0,N)
+    res['softmax_cols']=lib.hallo_softmax_rows(p,p,4,6,1.0,0,N)
+    res['copy2d_null']=lib.hallo_copy2d(N,8,N,8,4,8,0,N)
+    res['copy2d_w']=lib.hallo_copy2d(p,8,p,8,4,6,0,N)
+    res['nchw_null']=lib.hallo_nchw_to_nhwc(N,N,1,4,16,8,0,0,N)
+    res['nhwc_null']=lib.hallo_nhwc_to_nchw_f32(N,N,1,4,16,8,1.0,0.0,0.0,1.0,0,N)
+    res['rowstats_null']=lib.hallo_row_stats(N,N,4,320,1e-5,0,N)
+    res['face_null']=lib.hallo_face_xattn(N,N,N,N,N,N,N,32,320,32,1e-5,0,N)
+    res['face_C']=lib.hallo_face_xattn(p,p,p,p,p,p,p,32,40,32,1e-5,0,N)
+    res['u8_null']=lib.hallo_frames_to_uint8(N,N,1,3,16,N)
+    res['temb_null']=lib.hallo_timestep_embedding(N,N,1,320,0,N)
+    res['ddim_null']=lib.hallo_cfg_ddim_step(N,8,N,N,8,4,4,0,1.0,0.5,0.6,0,N)
+    res['ddim_alpha']=lib.hallo_cfg_ddim_step(p,8,p,p,8,4,4,0,1.0,1.5,0.6,0,N)
+    res['w2v_ws_bad']=lib.hallo_w2v_conv0_workspace(4,512,10,5)
+    res['w2v_null']=lib.hallo_w2v_conv0_gn_gelu(N,16000,N,N,N,N,N,512,10,5,1e-5,0,N)
+    res['w2v_k']=lib.hallo_w2v_conv0_gn_gelu(p,16000,p,p,p,p,p,512,17,5,1e-5,0,N)
+    res['lerp_null']=lib.hallo_lerp_rows(N,N,4,8,512,0,N)
+    res['lerp_C']=lib.hallo_lerp_rows(p,p,4,8,20,0,N)
+    res['opt_unknown']=lib.hallo_set_option(b"nope",1); res['get_unknown']=lib.hallo_get_option(b"nope")
+    bad = {k: v for k, v in res.items() if v != -22}
+    assert not bad, bad
+    assert len(res) >= 36
+    assert lib.hallo_groupnorm_chunks(4096) > 0
