@@ -115,6 +115,11 @@ class _FeatureEncoder(nn.Module):
         return None
 
     def run(self, wave, dtype):
+        n = wave.numel()
+        for layer in self.conv_layers:
+            n = layer.out_len(n)
+        if n < 1:
+            raise ValueError(f"waveform of {wave.numel()} samples is shorter than the feature encoder's receptive field")
         l0 = self.conv_layers[0]
         h = ops.w2v_conv0_gn_gelu(wave, l0.w0, l0.g0, l0.b0, l0.k, l0.stride, 1e-5, dtype)
         for layer in self.conv_layers[1:]:

@@ -170,3 +170,29 @@ def test_audio_processor_host_logic(emu, tmp_path):
     assert x.shape == (4000,) and np.abs(x - pcm.astype(np.float32) / 32768.0).max() == 0.0
     with pytest.raises(ValueError):
         load_wav(path, 22050)
+
+
+@pytest.mark.parametrize("n,seq_len", [(400, 1), (401, 3), (1000, 8), (640, 1)])
+def test_native_edge_lengths(emu, n, seq_len):
+    """Shortest waveform the conv stack accepts (400 samples -> one feature frame), a single output frame, exactly one
+    padding block."""
+    cfg = W.TINY_CONFIG
+    sd = W.synthetic_state_dict(cfg, seed=6)
+    m = _native(cfg, sd)
+    x = torch.randn((1, n), generator=torch.Generator().manual_seed(n))
+    with torch.no_grad():
+        ref = W.wav2vec_forward(sd, cfg, x, seq_len)
+    out = m(x, seq_len=seq_len, output_hidden_states=True)
+    for r, o in zip(ref, out.hidden_states):
+        assert o.shape == r.shape == (1, seq_len, 64)
+        assert (r - o).abs().max().item() < 1e-4
+
+
+def test_native_rejects_too_short_and_batched_input(emu):
+    m = _native(W.TINY_CONFIG, W.synthetic_state_dict(W.TINY_CONFIG, seed=6))
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 4000), seq_len=4)                       # one utterance per call
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 1, 4000), seq_len=4)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 399), seq_len=1)                        # below the conv stack's receptive field (400 samples)
