@@ -79,3 +79,17 @@ class AudioProcessor:
 
     def preprocess(self, wav_file, clip_length=-1):
         return self.preprocess_array(load_wav(wav_file, self.sample_rate), clip_length)
+
+    def get_embedding(self, wav_file):
+        """audio_processor.py:130-164: `preprocess` without the clip_length padding; returns the embedding only."""
+        return self.preprocess_array(load_wav(wav_file, self.sample_rate), clip_length=-1)[0]
+
+    # context-manager surface of the reference (audio_processor.py:166-176)
+    def close(self):
+        return self
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, _exc_type, _exc_val, _exc_tb):
+        self.close()

@@ -168,6 +168,12 @@ def test_audio_processor_host_logic(emu, tmp_path):
         f.writeframes(np.stack([pcm, pcm], axis=1).tobytes())
     x = load_wav(path, 16000)
     assert x.shape == (4000,) and np.abs(x - pcm.astype(np.float32) / 32768.0).max() == 0.0
+    with AudioProcessor(16000, 25, m) as proc:                      # file entry points: preprocess / get_embedding
+        e1, n1 = proc.preprocess(path, clip_length=4)
+        e2 = proc.get_embedding(path)
+    ref, ref_len = W.audio_embedding(sd, cfg, x, 16000, 25, 4)
+    assert n1 == ref_len == 7 and e1.shape == ref.shape == (8, 2, 64) and (e1 - ref).abs().max().item() < 1e-4
+    assert e2.shape == (7, 2, 64)
     with pytest.raises(ValueError):
         load_wav(path, 22050)
 
