@@ -279,3 +279,33 @@ def test_inference_plumbing_waveform_to_frames(emu, oracle):
                           img_size=(S, S), inference_steps=steps, cfg_scale=gs, motion_scale=ms, audio_length=len_n)
     assert vn.shape == vo.shape == (3, 4, S, S)
     assert Hn.psnr(vn, vo) > 55.0
+
+
+def test_pipeline_call_variants(emu, oracle):
+    """API variants of FaceAnimatePipeline.__call__ that the other tests do not touch: return_dict=False, callback_steps,
+    decode=False (latents out), generator-drawn latents (prepare_latents on the CPU generator) and a 5-D / 4-D ref_image."""
+    from oracle import harness as Hn
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline, FaceAnimatePipelineOutput
+    from hallo_amd.scheduler import DDIMScheduler
+    n = _native(oracle)
+    S, Fr, steps = 64, 2, 3
+    d = Hn.clip_inputs(S, Fr)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched)
+    args = (d["ref_image"], d["face_emb"], d["audio"], d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr, steps, 3.5)
+    seen = []
+    out = pipe(*args, motion_scale=d["motion_scale"], generator=torch.Generator().manual_seed(5), callback_steps=2,
+               callback=lambda i, t, l: seen.append(i))
+    assert isinstance(out, FaceAnimatePipelineOutput) and out.videos.shape == (1, 3, Fr, S, S)
+    assert seen == [0, 2]
+    vid = pipe(*args, motion_scale=d["motion_scale"], generator=torch.Generator().manual_seed(5), return_dict=False)
+    assert torch.equal(vid, out.videos)                                            # same seed, same frames
+    lat = pipe(*args, motion_scale=d["motion_scale"], generator=torch.Generator().manual_seed(5), decode=False)
+    assert lat.shape == (1, 4, Fr, S // 8, S // 8) and lat.dtype == torch.float32
+    flat = d["ref_image"].reshape(3, 3, S, S)                                      # (b f) c h w instead of b f c h w
+    vid4 = pipe(flat, *args[1:], motion_scale=d["motion_scale"], generator=torch.Generator().manual_seed(5), return_dict=False)
+    assert torch.equal(vid4, vid)
+    with pytest.raises(ValueError):
+        pipe(*args, eta=0.5)
