@@ -2,10 +2,10 @@
 """bench.py -- generated frames/sec of the Hallo denoising hot path on MI355X.
 
 Metric (BASELINE.json): generated frames/sec at 512x512, 16-frame window, 25 DDIM steps.
-Workload at every N (weak scaling): BASELINE config #2 per GPU -- one clip = FaceAnimatePipeline.__call__
+Workload at every N (weak scaling): BASELINE.json configs[1] per GPU -- one clip = FaceAnimatePipeline.__call__
 on synthetic inputs already resident in HBM: face tokens + VAE-encode(3) + FaceLocator + ReferenceNet write
 + 25 x (UNet3D, B=1, no CFG) + fused DDIM + batched VAE decode(16) + D2H of the fp32 frames; for N > 1 one
-RCCL all-gather of the decoded frames per wave of clips (BASELINE config #4's exchange).
+RCCL all-gather of the decoded frames per wave of clips (BASELINE.json configs[3]'s exchange).
 A "step" = one clip per rank.  bf16 storage, fp32 accumulation, random-init weights of the reference
 architecture, synthetic inputs.
 
@@ -289,7 +289,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--ddim-steps", type=int, default=25)
-    ap.add_argument("--guidance", type=float, default=1.0, help="1.0 = BASELINE config #2 (no CFG); 3.5 = config #3")
+    ap.add_argument("--guidance", type=float, default=1.0, help="1.0 = BASELINE.json configs[1] (no CFG); 3.5 = configs[2]")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help="internal: child process of cpu_baseline()")
@@ -394,7 +394,7 @@ def main():
         "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic (random-init weights of the reference architecture, synthetic clip inputs)",
-        "config": {"workload": f"BASELINE config #{3 if args.guidance > 1.0 else 2} per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
+        "config": {"workload": f"BASELINE.json configs[{2 if args.guidance > 1.0 else 1}] per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
                                f"steps, guidance {args.guidance} ({'CFG, B=2' if args.guidance > 1 else 'no CFG, B=1'}), "
                                "ReferenceNet + VAE encode/decode + D2H inside the timed region",
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (" + RCCL all-gather of frames" if world > 1 else "")},

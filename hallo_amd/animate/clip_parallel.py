@@ -1,4 +1,4 @@
-"""Clip-parallel inference across the GPUs of one node (BASELINE config #4).
+"""Clip-parallel inference across the GPUs of one node (BASELINE configs[3]).
 
 The shardable unit of the Hallo hot path is one `FaceAnimatePipeline.__call__` (one sliding-window clip given its
 `ref_image = [ref, m1, m2]` triple and latents): rank r of W takes clips r, r+W, r+2W, ...; weights are replicated;

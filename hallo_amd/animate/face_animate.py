@@ -16,7 +16,7 @@ Execution plan (not the reference's):
 
 Deviation from the reference, on purpose: `guidance_scale <= 1` works (the reference doubles the audio
 tensor unconditionally, face_animate.py:377-379, and then dies in the audio cross-attention -- SURVEY F5);
-here nothing is doubled without CFG.  BASELINE config #2 (25 steps, no CFG) needs this.
+here nothing is doubled without CFG.  BASELINE configs[1] (25 steps, no CFG) needs this.
 """
 from dataclasses import dataclass
 
@@ -26,6 +26,7 @@ from .. import ops
 from ..models.attention import ClipCache
 from ..models.mutual_self_attention import ReferenceAttentionControl
 from ..models.unet_3d import pack_masks
+from .image_processor import preprocess_image
 
 
 @dataclass
@@ -111,6 +112,7 @@ class FaceAnimatePipeline:
 
         # -- reference + motion frames -> latents (face_animate.py:332-336)
         imgs = ref_image.reshape(-1, *ref_image.shape[2:]) if ref_image.dim() == 5 else ref_image
+        imgs = preprocess_image(imgs, height, width, normalize=True)                # ref_image_processor.preprocess (:119-121, 333)
         n_ref = imgs.shape[0]
         ref_lat, _, _ = self.vae.encode_tokens(self._image_tokens(imgs, dt), n_ref, height, width, scale=0.18215)
 
@@ -139,7 +141,7 @@ class FaceAnimatePipeline:
             v = den.forward_tokens(x_in, int(t), enc, den.reference_bank, audio, mask_cond, masks, motion_scale, B, Fr,
                                    h, w, do_cfg, cache)
             a_t, a_p = self.scheduler.step_alphas(t)
-            ops.cfg_ddim_step(v, lat, x_in, Fr * L, C_lat, do_cfg, guidance_scale, a_t, a_p)
+            ops.cfg_ddim_step(v, lat, x_in, Fr * L, C_lat, do_cfg, guidance_scale, a_t, a_p, self.scheduler.step_mode)
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, lat.view(Fr, h, w, C_lat).permute(3, 0, 1, 2).unsqueeze(0).to(dt))
         reader.clear()

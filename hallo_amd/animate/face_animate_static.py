@@ -12,45 +12,18 @@ already-preprocessed tensors.
 """
 from dataclasses import dataclass
 
-import numpy as np
 import torch
 
 from .. import ops
 from ..models.attention import ClipCache
 from ..models.mutual_self_attention import ReferenceAttentionControl
 from .face_animate import FaceAnimatePipeline
+from .image_processor import preprocess_image  # noqa: F401  (re-exported)
 
 
 @dataclass
 class StaticPipelineOutput:
     images: torch.Tensor
-
-
-def preprocess_image(image, height, width, normalize):
-    """diffusers VaeImageProcessor.preprocess (0.27.2) for the two processors StaticPipeline builds (:117-125):
-    ref_image_processor (do_convert_rgb, do_normalize) and cond_image_processor (do_convert_rgb, no normalisation).
-    PIL -> RGB, resize (lanczos) to (width, height), float32 / 255, NCHW, optional 2x - 1.  Tensors (n, 3, H, W) are taken
-    as already in network range: normalised only if `normalize` and no value is negative (diffusers' own rule)."""
-    if isinstance(image, torch.Tensor):
-        x = image if image.dim() == 4 else image.unsqueeze(0)
-        if x.shape[-2:] != (height, width):
-            raise ValueError(f"tensor images must already be {height}x{width}, got {tuple(x.shape[-2:])}")
-        x = x.float()
-        if normalize and float(x.min()) >= 0.0:
-            x = 2.0 * x - 1.0
-        return x
-    from PIL import Image
-    imgs = image if isinstance(image, (list, tuple)) else [image]
-    out = []
-    for im in imgs:
-        if not isinstance(im, Image.Image):
-            raise TypeError(f"expected a PIL image or a tensor, got {type(im)}")
-        im = im.convert("RGB")
-        if im.size != (width, height):
-            im = im.resize((width, height), resample=Image.LANCZOS)
-        out.append(np.asarray(im, dtype=np.float32) / 255.0)
-    x = torch.from_numpy(np.stack(out, axis=0)).permute(0, 3, 1, 2).contiguous()
-    return 2.0 * x - 1.0 if normalize else x
 
 
 class StaticPipeline(FaceAnimatePipeline):
@@ -105,7 +78,7 @@ class StaticPipeline(FaceAnimatePipeline):
             v = den.forward_tokens(x_in, int(t), enc, den.reference_bank, None, mask_cond, None, None, B, 1, h, w, do_cfg,
                                    cache)
             a_t, a_p = self.scheduler.step_alphas(t)
-            ops.cfg_ddim_step(v, lat, x_in, L, C_lat, do_cfg, guidance_scale, a_t, a_p)
+            ops.cfg_ddim_step(v, lat, x_in, L, C_lat, do_cfg, guidance_scale, a_t, a_p, self.scheduler.step_mode)
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, lat.view(1, h, w, C_lat).permute(3, 0, 1, 2).unsqueeze(0).to(dt))
         reader.clear()

@@ -17,6 +17,8 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
+from .models.layers import reset_parameters_
+
 SAFETENSORS_WEIGHTS_NAME = "diffusion_pytorch_model.safetensors"
 WEIGHTS_NAME = "diffusion_pytorch_model.bin"
 
@@ -84,10 +86,17 @@ def load_unet3d_pretrained_2d(cls, pretrained_model_path, motion_module_path, su
         state_dict.update(motion_state_dict)
 
     model_state_dict = model.state_dict()
+    mismatched = []
     for k in state_dict:
         if k in model_state_dict and state_dict[k].shape != model_state_dict[k].shape:
             state_dict[k] = model_state_dict[k]
+            mismatched.append(k)
     missing, unexpected = model.load_state_dict(state_dict, strict=False)
+    # keys the checkpoints do not provide (audio modules, zero_conv_*, motion proj_out under mm_zero_proj_out) or provide in
+    # another shape (8-channel conv_in / conv_out with use_landmark) keep the reference's FRESH initialisation, never
+    # uninitialised memory: zeros where the reference zero-initialises, torch's default init elsewhere
+    fresh = [k for k in list(missing) + mismatched if k in dict(model.named_parameters())]
+    reset_parameters_(model, fresh)
     model.loading_info = {"missing_keys": list(missing), "unexpected_keys": list(unexpected)}
     return model
 

@@ -604,13 +604,15 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, T* __rest
 }
 
 // ------------------------------------------------------------------------------------------
-// CFG combine + DDIM v-prediction step (eta = 0), fp32 latents updated in place.
+// CFG combine + DDIM step (eta = 0; v / epsilon / sample prediction, optional clip_sample), fp32 latents updated in place.
+// `flags`: bit 0 CFG, bit 1 epsilon prediction, bit 2 sample prediction (neither: v-prediction), bit 3 clip x0 to [-1, 1].
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void cfg_ddim_kernel(const T* __restrict__ mo, long ldm, float* __restrict__ lat,
-                                                       T* __restrict__ nxt, long ldn, long rows, int C, int cfg,
+                                                       T* __restrict__ nxt, long ldn, long rows, int C, int flags,
                                                        float gs, float sa_t, float sb_t, float sa_p, float sb_p) {
   const long total = rows * C;
+  const int cfg = flags & 1;
   for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
     const long r = u / C;
     const int c = (int)(u - r * C);
@@ -623,8 +625,11 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const T* __restrict__ mo,
       v = to_f32(mo[r * ldm + c]);
     }
     const float xs = lat[u];
-    const float x0 = sa_t * xs - sb_t * v;
-    const float ep = sa_t * v + sb_t * xs;
+    float x0, ep;
+    if (flags & 2) { ep = v; x0 = (xs - sb_t * v) / sa_t; }            // epsilon prediction
+    else if (flags & 4) { x0 = v; ep = (xs - sa_t * v) / sb_t; }       // sample prediction
+    else { x0 = sa_t * xs - sb_t * v; ep = sa_t * v + sb_t * xs; }     // v-prediction
+    if (flags & 8) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                 // clip_sample (range 1.0); eps is NOT recomputed
     const float xp = sa_p * x0 + sb_p * ep;
     lat[u] = xp;
     if (nxt) {
@@ -844,6 +849,7 @@ extern "C" int hallo_cfg_ddim_step(const void* model_out, int64_t ldm, float* la
                                    int rows, int C, int cfg, float guidance_scale, float alpha_t, float alpha_prev,
                                    int dtype, void* stream) {
   if (!model_out || !latents || rows <= 0 || C <= 0 || ldm < C || (next_in && ldn < C)) return -22;
+  if (cfg < 0 || cfg > 15 || (cfg & 6) == 6) return -22;
   if (alpha_t < 0.0f || alpha_t > 1.0f || alpha_prev < 0.0f || alpha_prev > 1.0f) return -22;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const float sa_t = sqrtf(alpha_t), sb_t = sqrtf(1.0f - alpha_t);

@@ -20,8 +20,43 @@ from torch import nn
 from .. import ops
 
 
-def _param(*shape):
-    return nn.Parameter(torch.empty(*shape), requires_grad=False)
+def _param(*shape, one=False):
+    """Parameters are never left as uninitialised memory: zeros (norm scales: ones) at construction -- cheap (no 1.5 G-element
+    random draw) and finite; `reset_parameters_` gives the reference's fresh initialisation to the keys a checkpoint lacks."""
+    return nn.Parameter(torch.ones(*shape) if one else torch.zeros(*shape), requires_grad=False)
+
+
+def reset_parameters_(module, names=None, seed=0):
+    """The reference's *fresh* initialisation for the parameters `names` of `module` (None: all), i.e. what its modules hold
+    for keys a checkpoint does not provide: torch's default Linear / Conv init U(+-1/sqrt(fan_in)) for weights and biases,
+    1 / 0 for norm scale / shift, zeros for the layers the reference zero-initialises (`zero_module`: zero_conv_*,
+    hallo/models/attention.py; the motion module's temporal_transformer.proj_out, motion_module.py:140-145; FaceLocator's
+    conv_out, face_locator.py).  Values are drawn per parameter NAME from a CPU generator (reproducible)."""
+    import hashlib
+    params = dict(module.named_parameters())
+    for name in (sorted(params) if names is None else names):
+        p = params[name]
+        leaf = name.rsplit(".", 1)[-1]
+        is_norm = (".norm" in name or name.startswith("norm") or "conv_norm_out" in name or "group_norm" in name
+                   or ".norms." in name or "ff_norm" in name)
+        zero_init = ("zero_conv" in name or "temporal_transformer.proj_out." in name
+                     or (name.startswith("conv_out.") and module.__class__.__name__ == "FaceLocator"))
+        with torch.no_grad():
+            if zero_init:
+                p.zero_()
+            elif is_norm and p.dim() == 1:
+                p.fill_(1.0 if leaf == "weight" else 0.0)
+            else:
+                if p.dim() > 1:
+                    fan_in = p[0].numel()
+                else:       # a bias: fan-in of its layer's weight
+                    w = params.get(name[: -len(leaf)] + "weight")
+                    fan_in = w[0].numel() if w is not None and w.dim() > 1 else p.numel()
+                h = int.from_bytes(hashlib.sha256(f"{seed}:{name}".encode()).digest()[:8], "little") & 0x7FFFFFFFFFFFFFFF
+                g = torch.Generator().manual_seed(h)
+                bound = 1.0 / math.sqrt(fan_in)
+                p.copy_(((torch.rand(p.shape, generator=g) * 2 - 1) * bound).to(device=p.device, dtype=p.dtype))
+    return module
 
 
 class HalloModule(nn.Module):
@@ -132,7 +167,7 @@ class GroupNorm(nn.Module):
     def __init__(self, groups, channels, eps):
         super().__init__()
         self.groups, self.eps = groups, eps
-        self.weight = _param(channels)
+        self.weight = _param(channels, one=True)
         self.bias = _param(channels)
 
     def run(self, x, silu=False):
@@ -144,7 +179,7 @@ class LayerNorm(nn.Module):
     def __init__(self, dim, eps=1e-5):
         super().__init__()
         self.eps = eps
-        self.weight = _param(dim)
+        self.weight = _param(dim, one=True)
         self.bias = _param(dim)
 
     def run(self, x, **kw):

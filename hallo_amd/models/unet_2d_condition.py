@@ -22,7 +22,11 @@ from .transformer_2d import Transformer2DModel
 
 
 class _Config(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, name):          # a missing key is an AttributeError: hasattr / getattr(cfg, k, default) work
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
 
 def _cat_channels(a, b):

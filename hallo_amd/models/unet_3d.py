@@ -44,7 +44,11 @@ class HalloHipAttnProcessor:
 
 
 class _Config(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, name):          # a missing key is an AttributeError: hasattr / getattr(cfg, k, default) work
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
 
 class UNet3DConditionModel(HalloModule):

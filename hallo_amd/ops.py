@@ -328,13 +328,18 @@ def timestep_embedding(t, dim, dtype):
     return out
 
 
-def cfg_ddim_step(model_out, latents, next_in, rows, Cdim, cfg, guidance_scale, alpha_t, alpha_prev):
-    """In-place DDIM (eta=0, v-prediction) update of fp32 latents [rows, C] from model_out [(2)rows, ldm]."""
+DDIM_PRED = {"v_prediction": 0, "epsilon": 2, "sample": 4}       # HALLO_DDIM_PRED_* of include/hallo_amd.h
+DDIM_CLIP_SAMPLE = 8
+
+
+def cfg_ddim_step(model_out, latents, next_in, rows, Cdim, cfg, guidance_scale, alpha_t, alpha_prev, mode=0):
+    """In-place DDIM (eta=0) update of fp32 latents [rows, C] from model_out [(2)rows, ldm]; `mode` = DDIM_PRED[type]
+    (| DDIM_CLIP_SAMPLE), default v-prediction without clipping."""
     _chk_dev(model_out, latents)
     assert latents.dtype == torch.float32 and latents.is_contiguous()
     _l.check(_l.load().hallo_cfg_ddim_step(_p(model_out), model_out.stride(-2), _p(latents), _p(next_in),
                                            next_in.stride(-2) if next_in is not None else 0, rows, Cdim,
-                                           1 if cfg else 0, float(guidance_scale), float(alpha_t), float(alpha_prev),
+                                           (1 if cfg else 0) | int(mode), float(guidance_scale), float(alpha_t), float(alpha_prev),
                                            dtype_code(model_out.dtype), _stream()), "hallo_cfg_ddim_step")
     return latents
 

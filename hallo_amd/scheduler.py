@@ -26,7 +26,13 @@ def rescale_zero_terminal_snr(betas):
 
 
 class _Cfg(dict):
-    __getattr__ = dict.__getitem__
+    """Attribute view of the config dict; a missing key is an AttributeError so hasattr / getattr(cfg, k, default) work."""
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
 
 class DDIMScheduler:
@@ -35,8 +41,17 @@ class DDIMScheduler:
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                  clip_sample=True, set_alpha_to_one=True, steps_offset=0, prediction_type="epsilon",
-                 timestep_spacing="leading", rescale_betas_zero_snr=False, **unused):
-        self.config = _Cfg(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                 timestep_spacing="leading", rescale_betas_zero_snr=False, thresholding=False, clip_sample_range=1.0,
+                 **unused):
+        # everything the fused step kernel does not implement is refused HERE, never silently ignored
+        if prediction_type not in ("v_prediction", "epsilon", "sample"):
+            raise ValueError(f"prediction_type {prediction_type!r}: v_prediction, epsilon or sample")
+        if thresholding:
+            raise NotImplementedError("DDIMScheduler(thresholding=True) is not implemented by hallo_cfg_ddim_step")
+        if clip_sample and float(clip_sample_range) != 1.0:
+            raise NotImplementedError("clip_sample_range != 1.0 is not implemented by hallo_cfg_ddim_step")
+        self.config = _Cfg(thresholding=False, clip_sample_range=1.0,
+                           num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
                            beta_schedule=beta_schedule, clip_sample=clip_sample, set_alpha_to_one=set_alpha_to_one,
                            steps_offset=steps_offset, prediction_type=prediction_type,
                            timestep_spacing=timestep_spacing, rescale_betas_zero_snr=rescale_betas_zero_snr)
@@ -72,6 +87,12 @@ class DDIMScheduler:
         else:
             raise ValueError(sp)
         self.timesteps = torch.from_numpy(ts)   # host-side: indexing never syncs with the device
+
+    @property
+    def step_mode(self):
+        """`mode` of ops.cfg_ddim_step (HALLO_DDIM_PRED_* | HALLO_DDIM_CLIP_SAMPLE) for this scheduler's configuration."""
+        from .ops import DDIM_CLIP_SAMPLE, DDIM_PRED
+        return DDIM_PRED[self.config.prediction_type] | (DDIM_CLIP_SAMPLE if self.config.clip_sample else 0)
 
     def step_indices(self, timestep):
         """(t, prev_t) as python ints."""

@@ -216,14 +216,22 @@ int hallo_nhwc_to_nchw_f32(const void* x, float* y, int n, int C, int HW, int64_
  * (hallo/models/unet_3d.py:184-185,582): out[b, :] = [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(1e4)*i/half). */
 int hallo_timestep_embedding(const float* t, void* out, int batch, int dim, int dtype, void* stream);
 
-/* hallo_cfg_ddim_step: classifier-free guidance combine + DDIM (eta = 0) v-prediction update
- * (hallo/animate/face_animate.py:415-420; diffusers DDIMScheduler.step):
+/* hallo_cfg_ddim_step: classifier-free guidance combine + DDIM (eta = 0) update
+ * (hallo/animate/face_animate.py:415-420; diffusers DDIMScheduler.step).  `cfg` is a flag word:
+ *   HALLO_DDIM_CFG (1) guidance, HALLO_DDIM_PRED_EPSILON (2) / HALLO_DDIM_PRED_SAMPLE (4) prediction_type
+ *   (neither: v_prediction, what configs/inference/default.yaml:82 sets), HALLO_DDIM_CLIP_SAMPLE (8) clip x0 to [-1, 1].
  *   v      = guidance ? uncond + gs * (cond - uncond) : model_out
- *   x0     = sqrt(a_t) * x - sqrt(1 - a_t) * v ; eps = sqrt(a_t) * v + sqrt(1 - a_t) * x
+ *   v-pred:  x0 = sqrt(a_t) * x - sqrt(1 - a_t) * v ; eps = sqrt(a_t) * v + sqrt(1 - a_t) * x
+ *   epsilon: eps = v ; x0 = (x - sqrt(1 - a_t) * v) / sqrt(a_t)      sample: x0 = v ; eps = (x - sqrt(a_t) * v) / sqrt(1 - a_t)
+ *   clip_sample: x0 = clamp(x0, -1, 1) (eps is not recomputed: use_clipped_model_output = False)
  *   x_prev = sqrt(a_prev) * x0 + sqrt(1 - a_prev) * eps
  * model_out: dtype [B*F, HW, ldm] token-major (cond batch follows uncond batch when cfg=1),
  * latents: fp32 [F, HW, C] token-major, updated in place; next_in: dtype [F, HW, ldn] (the next
  * UNet input, channels >= C zero) written for both CFG halves by the caller's layout. */
+#define HALLO_DDIM_CFG 1
+#define HALLO_DDIM_PRED_EPSILON 2
+#define HALLO_DDIM_PRED_SAMPLE 4
+#define HALLO_DDIM_CLIP_SAMPLE 8
 int hallo_cfg_ddim_step(const void* model_out, int64_t ldm, float* latents, void* next_in, int64_t ldn,
                         int rows, int C, int cfg, float guidance_scale, float alpha_t, float alpha_prev,
                         int dtype, void* stream);

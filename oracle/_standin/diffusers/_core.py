@@ -836,6 +836,9 @@ class DDIMScheduler:
         elif pt == "v_prediction":
             pred_original_sample = (alpha_prod_t ** 0.5) * sample - (beta_prod_t ** 0.5) * model_output
             pred_epsilon = (alpha_prod_t ** 0.5) * model_output + (beta_prod_t ** 0.5) * sample
+        elif pt == "sample":
+            pred_original_sample = model_output
+            pred_epsilon = (sample - alpha_prod_t ** 0.5 * pred_original_sample) / beta_prod_t ** 0.5
         else:
             raise ValueError(pt)
         if self.config.clip_sample:
@@ -891,12 +894,25 @@ class DiffusionPipeline:
 
 
 class VaeImageProcessor:
+    """Tensor branch of diffusers 0.27.2 `VaeImageProcessor.preprocess` (image_processor.py): 4-channel inputs are latents
+    and pass through; otherwise height / width are rounded down to a multiple of vae_scale_factor, the image is resized
+    with `F.interpolate(size=...)` (nearest) when do_resize, and normalised `2x - 1` when do_normalize UNLESS it holds a
+    negative value (diffusers warns and skips: the input is taken as already in [-1, 1])."""
+
     def __init__(self, do_resize=True, vae_scale_factor=8, resample="lanczos", do_normalize=True,
                  do_binarize=False, do_convert_rgb=False, do_convert_grayscale=False):
         self.vae_scale_factor = vae_scale_factor
+        self.do_resize, self.do_normalize = do_resize, do_normalize
 
     def preprocess(self, image, height=None, width=None):
         assert isinstance(image, torch.Tensor) and image.ndim == 4
-        if height is not None and (image.shape[-2] != height or image.shape[-1] != width):
+        if image.shape[1] == 4:
+            return image
+        height = image.shape[-2] if height is None else height
+        width = image.shape[-1] if width is None else width
+        height, width = (x - x % self.vae_scale_factor for x in (height, width))
+        if self.do_resize and (image.shape[-2] != height or image.shape[-1] != width):
             image = F.interpolate(image, size=(height, width))
+        if self.do_normalize and not image.min() < 0:
+            image = 2.0 * image - 1.0
         return image

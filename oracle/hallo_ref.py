@@ -953,7 +953,14 @@ def animate(vae, reference_unet, denoising_unet, face_locator, image_proj, sched
         shape = (1, 4, video_length, height // vae_scale, width // vae_scale)
         latents = randn_tensor(shape, generator=generator, device=torch.device("cpu"), dtype=dtype)
     latents = latents * scheduler.init_noise_sigma
-    ref = rearrange(ref_image, "b f c h w -> (b f) c h w").to(dtype)
+    # ref_image_processor.preprocess (face_animate.py:119-121, 333): nearest resize to (height, width), 2x - 1 unless a
+    # value is negative (diffusers 0.27.2 VaeImageProcessor, tensor branch)
+    ref = rearrange(ref_image, "b f c h w -> (b f) c h w")
+    if tuple(ref.shape[-2:]) != (height, width):
+        ref = F.interpolate(ref, size=(height, width))
+    if not ref.min() < 0:
+        ref = 2.0 * ref - 1.0
+    ref = ref.to(dtype)
     ref_latents = vae.encode(ref).latent_dist.mean * 0.18215
     fm = face_mask.unsqueeze(1).to(dtype)
     fm = repeat(fm, "b f c h w -> b (repeat f) c h w", repeat=video_length).transpose(1, 2)

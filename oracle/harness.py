@@ -24,29 +24,62 @@ SMALL_AUDIO_DIM = 48
 ZERO_INIT_STD = 0.1
 SMALL_VAE = dict(block_out_channels=(32, 32, 64, 64), norm_num_groups=16)
 FULL = dict(block_out_channels=(320, 640, 1280, 1280), attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32)
+FULL_AUDIO_DIM = 768
+FULL_VAE = dict(block_out_channels=(128, 256, 512, 512), norm_num_groups=32)     # sd-vae-ft-mse
+FULL_ZERO_INIT_STD = 0.03            # of the order of the fan-in bound of the full-width zero-init layers (1/sqrt(1280))
+BOTH = "both"                        # pseudo-dtype: values exactly representable in fp16 AND bf16
+
+
+def round_both(v):
+    """fp32 values that survive both an fp16 and a bf16 cast unchanged: bf16's 8 significant bits inside fp16's normal
+    exponent range (|v| < 2^-14 flushed to zero; synthetic weights / inputs never come near fp16's 65504 ceiling).
+    One fp32 oracle evaluation on such weights and inputs is the target of the fp16 AND of the bf16 native run."""
+    v = v.to(torch.bfloat16).float()
+    return torch.where(v.abs() < 2.0 ** -14, torch.zeros_like(v), v)
 
 
 def round_to(sd, dtype):
     """Round every floating tensor through `dtype` (what loading an fp16/bf16 checkpoint does) -> fp32."""
-    return {k: (v.to(dtype).float() if v.is_floating_point() else v) for k, v in sd.items()}
+    f = round_both if dtype == BOTH else (lambda v: v.to(dtype).float())
+    return {k: (f(v) if v.is_floating_point() else v) for k, v in sd.items()}
 
 
-def oracle_nets(cfg=SMALL, audio_dim=SMALL_AUDIO_DIM, vae_cfg=SMALL_VAE, dtype=torch.float16, seed=0):
-    """Oracle modules (fp32 compute) whose weights are synthetic values rounded through `dtype`."""
+class fast_init:
+    """Skip torch's default (kaiming / normal) parameter initialisation while the oracle modules are constructed: every
+    parameter is overwritten by fill_synthetic_ right after, and at full width the default init costs ~45 s of the
+    test budget.  Buffers (positional encodings, schedules) are computed as usual."""
+
+    def __enter__(self):
+        import torch.nn as nn
+        self._saved = [(c, c.reset_parameters) for c in (nn.Linear, nn.modules.conv._ConvNd, nn.Embedding)]
+        for c, _ in self._saved:
+            c.reset_parameters = lambda self: None
+        return self
+
+    def __exit__(self, *exc):
+        for c, f in self._saved:
+            c.reset_parameters = f
+        return False
+
+
+def oracle_nets(cfg=SMALL, audio_dim=SMALL_AUDIO_DIM, vae_cfg=SMALL_VAE, dtype=torch.float16, seed=0,
+                zero_init_std=ZERO_INIT_STD):
+    """Oracle modules (fp32 compute) whose weights are synthetic values rounded through `dtype` (or BOTH)."""
     from diffusers import AutoencoderKL
     mm = SMALL_MM if cfg is SMALL else None
-    den = H.UNet3DConditionModel(audio_attention_dim=audio_dim, motion_module_kwargs=mm, **cfg)
-    ref = H.UNet2DConditionModel(**cfg)
-    vae = AutoencoderKL(**vae_cfg)
-    c0 = cfg["block_out_channels"][0]
-    fl = H.FaceLocator(c0)
-    ip = H.ImageProjModel(cfg["cross_attention_dim"], 512, 4)
-    ap = H.AudioProjModel(5, 12, 16, 32, audio_dim, 32)
+    with fast_init():
+        den = H.UNet3DConditionModel(audio_attention_dim=audio_dim, motion_module_kwargs=mm, **cfg)
+        ref = H.UNet2DConditionModel(**cfg)
+        vae = AutoencoderKL(**vae_cfg)
+        c0 = cfg["block_out_channels"][0]
+        fl = H.FaceLocator(c0)
+        ip = H.ImageProjModel(cfg["cross_attention_dim"], 512, 4)
+        ap = H.AudioProjModel(5, 12, 16, 32, audio_dim, 32)
     nets = dict(denoising_unet=den, reference_unet=ref, vae=vae, face_locator=fl, imageproj=ip, audioproj=ap)
     for i, (name, m) in enumerate(nets.items()):
         # zero-init layers get std 0.1 (the order of their fan-in bound) so the audio / temporal / mask paths
         # each move the output by several times the parity tolerance (tests/test_oracle_cpu.py checks that)
-        H.fill_synthetic_(m, seed + i + 1, zero_init_std=ZERO_INIT_STD)
+        H.fill_synthetic_(m, seed + i + 1, zero_init_std=zero_init_std)
         m.load_state_dict(round_to(m.state_dict(), dtype))
         m.eval()
     return nets

@@ -260,7 +260,7 @@ def timestep_embedding(t, dim, dtype):
     return torch.cat([torch.cos(a), torch.sin(a)], dim=1).to(dtype)
 
 
-def cfg_ddim_step(model_out, latents, next_in, rows, Cdim, cfg, guidance_scale, alpha_t, alpha_prev):
+def cfg_ddim_step(model_out, latents, next_in, rows, Cdim, cfg, guidance_scale, alpha_t, alpha_prev, mode=0):
     assert latents.dtype == torch.float32 and latents.is_contiguous()
     mo = model_out.float().reshape(-1, model_out.shape[-1])
     if cfg:
@@ -271,8 +271,15 @@ def cfg_ddim_step(model_out, latents, next_in, rows, Cdim, cfg, guidance_scale, 
     f = lambda s: float(np.sqrt(np.float32(s)))
     sa_t, sb_t, sa_p, sb_p = f(alpha_t), f(1.0 - np.float32(alpha_t)), f(alpha_prev), f(1.0 - np.float32(alpha_prev))
     xs = latents.view(rows, Cdim)
-    x0 = sa_t * xs - sb_t * v
-    ep = sa_t * v + sb_t * xs
+    if mode & 2:
+        ep, x0 = v, (xs - sb_t * v) / sa_t
+    elif mode & 4:
+        x0, ep = v, (xs - sa_t * v) / sb_t
+    else:
+        x0 = sa_t * xs - sb_t * v
+        ep = sa_t * v + sb_t * xs
+    if mode & 8:
+        x0 = x0.clamp(-1.0, 1.0)
     xp = sa_p * x0 + sb_p * ep
     xs.copy_(xp)
     if next_in is not None:

@@ -96,6 +96,13 @@ def test_from_pretrained_2d_matches_reference_loader(tmp_path, fmt, mm_suffix, z
     assert set(n.loading_info["missing_keys"]) == set(fresh)
     if zero_proj:
         assert all(("proj_out" in k) or ("motion_modules" not in k) for k in fresh if "motion_modules" in k or "proj_out" in k)
+    # ... and that fresh initialisation is the reference's, never uninitialised memory: everything finite, zeros where the
+    # reference zero-initialises (zero_conv_*, the motion modules' proj_out), non-trivial default init elsewhere
+    assert all(torch.isfinite(v).all() for v in nsd.values())
+    for k in fresh:
+        zero = "zero_conv" in k or "temporal_transformer.proj_out." in k
+        assert (float(nsd[k].abs().max()) == 0.0) == zero or ".norm" in k or "norm" in k.split(".")[-2], k
+        assert (float(rsd[k].abs().max()) == 0.0) == (float(nsd[k].abs().max()) == 0.0), k
 
 
 def test_from_pretrained_2d_stage1_matches_reference_loader(tmp_path):
@@ -129,6 +136,9 @@ def test_from_pretrained_2d_landmark_and_shape_rule(tmp_path):
     from hallo_amd.models.unet_3d import UNet3DConditionModel as Native
     n = Native.from_pretrained_2d(tmp, os.path.join(tmp, "absent.ckpt"), subfolder="unet", unet_additional_kwargs=_unet_kwargs())
     assert n.conv_in.weight.shape[1] == 8 and n.conv_out.weight.shape[0] == 8
+    for p in (n.conv_in.weight, n.conv_out.weight):          # fresh default init, not zeros and not garbage
+        assert torch.isfinite(p).all() and 0.0 < float(p.abs().max()) <= 1.0 / (9 * p.shape[1]) ** 0.5 + 1e-6
+    assert all(torch.isfinite(v).all() for v in n.state_dict().values())
     assert torch.equal(n.state_dict()["time_embedding.linear_1.weight"], sd2d["time_embedding.linear_1.weight"])
 
 

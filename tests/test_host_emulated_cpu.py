@@ -119,6 +119,77 @@ def test_pipeline_end_to_end(emu, oracle, guidance):
     assert Hn.psnr(vid_n, vid_o) > 60.0
 
 
+def test_pipeline_preprocesses_ref_image(emu, oracle):
+    """ref_image_processor.preprocess (hallo/animate/face_animate.py:119-121, 333; diffusers 0.27.2 VaeImageProcessor, tensor
+    branch): a [0, 1] reference image of another size is nearest-resized to (height, width) and mapped to [-1, 1] -- on the
+    native side as in the oracle (and in the stand-in the bit-exact oracle-vs-reference pin runs on)."""
+    from oracle import harness as Hn
+    from oracle import hallo_ref as H
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.scheduler import DDIMScheduler
+    o, n = oracle, _native(oracle)
+    S, Fr, steps, gs = 64, 2, 1, 1.0
+    d = Hn.clip_inputs(S, Fr)
+    ref01 = torch.rand((1, 3, 3, 96, 80), generator=torch.Generator().manual_seed(8))         # [0, 1], 96 x 80 -> 64 x 64
+    args = (ref01, d["face_emb"], d["audio"], d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr, steps, gs)
+    with torch.no_grad():
+        vid_o = H.animate(o["vae"], o["reference_unet"], o["denoising_unet"], o["face_locator"], o["imageproj"],
+                          H.make_scheduler(), *args, motion_scale=d["motion_scale"], latents=d["latents"])
+        # the rule itself: identical to handing over the resized, normalised image
+        pre = 2.0 * torch.nn.functional.interpolate(ref01[0], size=(S, S)) - 1.0
+        vid_pre = H.animate(o["vae"], o["reference_unet"], o["denoising_unet"], o["face_locator"], o["imageproj"],
+                            H.make_scheduler(), pre[None], *args[1:], motion_scale=d["motion_scale"], latents=d["latents"])
+    assert torch.equal(vid_o, vid_pre)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched)
+    vid_n = pipe(*args, motion_scale=d["motion_scale"], latents=d["latents"]).videos
+    assert Hn.psnr(vid_n, vid_o) > 60.0
+    # without the rule the frames differ visibly (the test can see the deviation ADVICE r1 pointed at)
+    raw = torch.nn.functional.interpolate(ref01[0], size=(S, S))[None]
+    with torch.no_grad():
+        vid_raw = H.animate(o["vae"], o["reference_unet"], o["denoising_unet"], o["face_locator"], o["imageproj"],
+                            H.make_scheduler(), raw - 1e-3, *args[1:], motion_scale=d["motion_scale"], latents=d["latents"])
+    assert Hn.psnr(vid_raw, vid_o) < 50.0
+
+
+def test_scheduler_modes(emu):
+    """DDIMScheduler consumes prediction_type / clip_sample: the fused step kernel's mode flags reproduce
+    diffusers' DDIMScheduler.step (eta = 0) for v / epsilon / sample prediction with and without clip_sample; options the
+    kernel does not implement are refused at construction."""
+    from oracle import harness  # noqa: F401  (puts the diffusers stand-in on the path)
+    from diffusers import DDIMScheduler as OracleSched
+    from hallo_amd import ops
+    from hallo_amd.scheduler import DDIMScheduler
+    g = torch.Generator().manual_seed(2)
+    for pt in ("v_prediction", "epsilon", "sample"):
+        for clip in (False, True):
+            kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=clip, steps_offset=1,
+                      prediction_type=pt, timestep_spacing="trailing")
+            so, sn = OracleSched(**kw), DDIMScheduler(**kw)
+            so.set_timesteps(4)
+            sn.set_timesteps(4)
+            assert [int(t) for t in so.timesteps] == [int(t) for t in sn.timesteps]
+            x = torch.randn((6, 4), generator=g) * 1.5
+            mo = torch.randn((12, 8), generator=g)
+            for t in sn.timesteps[1:3]:
+                v = mo[:6, :4] + 2.5 * (mo[6:, :4] - mo[:6, :4])
+                want = so.step(v, t, x).prev_sample
+                lat = x.clone()
+                a_t, a_p = sn.step_alphas(t)
+                ops.cfg_ddim_step(mo, lat, None, 6, 4, True, 2.5, a_t, a_p, sn.step_mode)
+                assert torch.allclose(lat, want, atol=2e-6, rtol=1e-5), (pt, clip)
+    with pytest.raises(NotImplementedError):
+        DDIMScheduler(thresholding=True)
+    with pytest.raises(NotImplementedError):
+        DDIMScheduler(clip_sample=True, clip_sample_range=2.0)
+    with pytest.raises(ValueError):
+        DDIMScheduler(prediction_type="flow")
+    cfg = DDIMScheduler().config
+    assert getattr(cfg, "no_such_key", 7) == 7 and not hasattr(cfg, "no_such_key") and cfg.clip_sample is True
+
+
 def test_sliding_window_driver(emu, oracle):
     """hallo_amd.animate.video.generate_video (motion-frame carry, audio windowing, one generator stream for all clips,
     trim to the audio length) vs the oracle driver around the oracle pipeline: 3 clips of 2 frames."""
@@ -212,8 +283,9 @@ def test_static_pipeline_pil_inputs():
     t = torch.rand((1, 3, 8, 8))
     assert torch.equal(preprocess_image(t, 8, 8, normalize=True), 2 * t - 1)             # in [0, 1]: normalised
     assert torch.equal(preprocess_image(t - 0.5, 8, 8, normalize=True), t - 0.5)         # already signed: kept
-    with pytest.raises(ValueError):
-        preprocess_image(t, 16, 16, normalize=False)
+    # tensors of another size: diffusers' tensor branch resizes with F.interpolate(size=...) (nearest)
+    assert torch.equal(preprocess_image(t, 16, 12, normalize=False), torch.nn.functional.interpolate(t, size=(16, 12)))
+    assert torch.equal(preprocess_image(t, 5, 3, normalize=True), 2 * torch.nn.functional.interpolate(t, size=(5, 3)) - 1)
 
 
 # wav2vec configuration whose hidden size is the harness AudioProjModel's `channels` (16) with the base model's 12 layers
@@ -223,7 +295,7 @@ W2V_PLUMBING = dict(conv_dim=(32,) * 7, conv_stride=(5, 2, 2, 2, 2, 2, 2), conv_
 
 
 def test_inference_plumbing_waveform_to_frames(emu, oracle):
-    """The whole chain of scripts/inference.py:166-347 behind the file / face-analysis I/O (BASELINE config #0's
+    """The whole chain of scripts/inference.py:166-347 behind the file / face-analysis I/O (BASELINE.json configs[0]'s
     "scripts/inference.py plumbing", scaled down): 16 kHz waveform -> AudioProcessor (normalise, pad to clip_length,
     wav2vec2, 12-layer stack) -> process_audio_emb windows -> AudioProjModel -> sliding-window clips with motion-frame
     carry -> frames trimmed to the audio length.  Native chain vs oracle chain, both fp32 on the CPU."""

@@ -590,6 +590,36 @@ def test_cfg_ddim_step(dtype, cfg, report):
         assert torch.equal(nxt[rows:, :Cd], lat.to(dtype))
 
 
+@pytest.mark.parametrize("pred", ["v_prediction", "epsilon", "sample"])
+@pytest.mark.parametrize("clip", [False, True])
+def test_cfg_ddim_step_modes(pred, clip, report):
+    """prediction_type / clip_sample flags of hallo_cfg_ddim_step vs diffusers' DDIMScheduler.step (eta = 0) restated in
+    torch: x0 / eps by prediction type, x0 clipped to [-1, 1] (eps not recomputed), x_prev = sqrt(a_p) x0 + sqrt(1 - a_p) eps."""
+    from hallo_amd import ops
+    g = torch.Generator().manual_seed(13)
+    rows, Cd, gs = 300, 4, 2.5
+    lat0 = (torch.randn((rows, Cd), generator=g) * 1.5).to(_dev())
+    mo = _rand((2 * rows, 8), torch.float16, g)
+    a_t, a_p = 0.2731, 0.6112
+    lat = lat0.clone()
+    ops.cfg_ddim_step(mo, lat, None, rows, Cd, True, gs, a_t, a_p, ops.DDIM_PRED[pred] | (ops.DDIM_CLIP_SAMPLE if clip else 0))
+    m = mo.float()[:, :Cd]
+    v = m[:rows] + gs * (m[rows:] - m[:rows])
+    sa, sb = a_t ** 0.5, (1 - a_t) ** 0.5
+    if pred == "epsilon":
+        x0, ep = (lat0 - sb * v) / sa, v
+    elif pred == "sample":
+        x0, ep = v, (lat0 - sa * v) / sb
+    else:
+        x0, ep = sa * lat0 - sb * v, sa * v + sb * lat0
+    if clip:
+        x0 = x0.clamp(-1, 1)
+    ref = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * ep
+    err = (lat - ref).abs().max().item()
+    report.append({"test": f"cfg_ddim_modes[{pred},clip={clip}]", "max_abs_err": err})
+    assert err < 2e-5, err
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,HW,Cd,silu", [(16, 256, 1280, True), (4, 1024, 640, False), (16, 64, 2560, True), (8, 100, 1920, True),
                                           (4, 256, 128, True), (2, 1024, 960, False)])

@@ -1,19 +1,16 @@
-"""GPU parity tests written after the round's GPU budget was spent -- they run last:
-the stage-1 StaticPipeline and the waveform-to-frames chain at BASELINE config #0's shape.
+"""GPU parity tests that run last: the stage-1 StaticPipeline and the waveform-to-frames chain at
+BASELINE.json configs[0]'s shape (config numbering everywhere in this repository: 0-based index into BASELINE.json "configs").
 
 The oracle side (oracle.hallo_ref.animate_static) is pinned bit-exact against the reference's own StaticPipeline
 (tests/test_oracle_vs_reference.py) and the native host logic against the oracle on CPU through the operator emulation
-(tests/test_host_emulated_cpu.py); the same holds for the waveform-to-frames chain.  The kernels are the clip pipeline's
-and the wav2vec front-end's, all verified on hardware in other shapes.  The first hardware run of this file is the
-driver's round-end run, hence the non-strict xfail marker (an XPASS is the expected outcome; remove the marker once
-seen green)."""
+(tests/test_host_emulated_cpu.py); the same holds for the waveform-to-frames chain.  First hardware run: the round-1
+driver run (GPUTEST_r01: all five cases green), so the file carries no xfail marker any more."""
 import pytest
 import torch
 
 DEV = "cuda:0"        # tests/test_emu_predicts_round_end_cpu.py replays these bodies on the CPU emulation with DEV = "cpu"
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="first hardware run happens at round end (GPU budget exhausted when built)")]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
@@ -55,7 +52,7 @@ def test_static_pipeline(dtype, guidance, report):
 
 
 def test_inference_plumbing_config0(report):
-    """BASELINE config #0 -- "1 clip, 256x256, 8 frames, 10 DDIM steps, random-init UNet/VAE/wav2vec, fixed seed
+    """BASELINE.json configs[0] -- "1 clip, 256x256, 8 frames, 10 DDIM steps, random-init UNet/VAE/wav2vec, fixed seed
     (scripts/inference.py plumbing)" -- on the reduced-width nets of oracle/harness.py: waveform -> AudioProcessor
     (wav2vec2, 12 layers) -> process_audio_emb -> AudioProjModel -> one sliding-window clip with CFG 3.5 -> frames.
     fp16 (the reference's default weight dtype), native chain on the GPU vs the oracle chain on the CPU."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Feasibility study for BASELINE config #5's "fp8 MFMA QKV/out projections" -- numerics only, on the CPU.
+"""Feasibility study for BASELINE.json configs[4]'s "fp8 MFMA QKV/out projections" -- numerics only, on the CPU.
 
 The native models run on the operator emulation of tests/emu_ops.py in bf16 storage (fp32 arithmetic inside an operator, one
 rounding at its output, as the kernels do); every GEMM whose weight belongs to an attention projection (to_q / to_k / to_v /
