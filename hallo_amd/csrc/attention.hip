@@ -20,23 +20,13 @@
 // (kv = 16*h2 + (j&3) + 8*(j>>2) + 4*hi for slot j of lane half hi), and the V^T fragment is read
 // from LDS with the same permutation (two 8-byte reads per fragment).
 #include "common.h"
+#include "attn_args.h"
 #include "../../include/hallo_amd.h"
 #include <type_traits>
 #include <string.h>
 
 namespace hallo {
 
-struct AttnArgs {
-  const void* q; const void* k1; const void* v1; const void* k2; const void* v2; void* o;
-  int batch, heads, Lq, Lkv1, Lkv2;
-  long q_bs, q_rs, k1_bs, k1_rs, v1_bs, v1_rs, k2_bs, k2_rs, v2_bs, v2_rs, o_bs, o_rs;
-  int kv2_div, kv2_mod, kv2_first;
-  float scale_log2e;
-  int nqb;  // query blocks per (batch, head)
-  const float* o_rowscale;   // optional fp32 output row scale: o[b, q, head h] *= o_rowscale[(h / rs_hdiv) * rs_stride + b * Lq + q]
-  int rs_hdiv;
-  long rs_stride;
-};
 
 // PRE = q already carries scale * log2(e) (hallo_gemm lead_alpha).  For head dim 40 the QK^T contraction is padded
 // to 48: pad column 40 of every K row in LDS is 1.0 and pad element 40 of the lane's Q row holds -m_run (kept exactly
@@ -649,6 +639,7 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const T* __rest
 }
 
 static int g_temporal_mfma = 1;   // hallo_set_option("temporal_mfma", 0 | 1)
+static int g_attn40 = 1;          // hallo_set_option("attn40", 0 | 1): head-dim-40 pre-scaled-q launches on attention40.hip
 
 }  // namespace hallo
 
@@ -675,6 +666,8 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
   a.rs_hdiv = d->o_rowscale_head_div > 0 ? d->o_rowscale_head_div : d->heads;
   a.rs_stride = d->o_rowscale_stride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (g_attn40 && d->head_dim == 40 && d->q_prescaled != 0 && (d->dtype == DT_F16 || d->dtype == DT_BF16))
+    return launch_attn40(a, d->dtype, st);          // attention40.hip: LDS-DMA staging + transposing V reads
   if (d->dtype == DT_F16) return launch_attn<_Float16>(a, d->head_dim, d->q_prescaled != 0, st);
   if (d->dtype == DT_BF16) return launch_attn<__bf16>(a, d->head_dim, d->q_prescaled != 0, st);
   return -22;
@@ -682,6 +675,7 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
 
 extern "C" int hallo_set_option_attn(const char* name, int value) {
   if (name && !strcmp(name, "temporal_mfma")) { if (value < 0 || value > 1) return -22; g_temporal_mfma = value; return 0; }
+  if (name && !strcmp(name, "attn40")) { if (value < 0 || value > 1) return -22; g_attn40 = value; return 0; }
   return -22;
 }
 

@@ -1,0 +1,371 @@
+// Flash-style attention for head dim 40 on gfx950: K/V tiles staged by LDS-DMA, V consumed with the transposing LDS read.
+//
+// Same operator as attention.hip's attn_kernel<T, 40, true> (diffusers AttnProcessor2_0 / F.scaled_dot_product_attention as
+// called from hallo/models/mutual_self_attention.py:253-284 -- K/V = [self ; reference bank], CFG uncond rows self only --
+// and hallo/models/attention.py:828-884), for q pre-scaled by head_dim^-1/2 * log2(e).  What changed, and why:
+//
+//  * On the hd-40 shapes the kernel is VALU-bound (r1 PMC: VALU busy 65-68 %, matrix pipe 40-45 %).  Per 64-key tile a wave
+//    needs 32 exp + 16 convert + 16 max3 for the softmax -- and spent ~25 more VALU / 10 LDS-write instructions on STAGING:
+//    global -> VGPR -> LDS for K, and a VGPR transpose (8 two-element packs + 8 ds_write_b32 per thread) to build V^T.
+//  * Here K and V go global -> LDS by DMA (`buffer_load_dwordx4 ... lds`, 16 B per lane, lane-linear destination): no staging
+//    registers, no address VALU in the loop (per-lane offsets are computed once per segment, the tile advance is the scalar
+//    offset), no LDS write instructions.  V stays ROW-major in LDS and the A operand of O^T += V^T . P^T is read with
+//    `ds_read_b64_tr_b16` (each 16-lane group fetches a [4 kv][16 d] block transposed): the V^T build disappears.
+//  * LDS images are dense and conflict-free without padding: K [64][40] at an 80-byte pitch (5 x 16 B, odd -> the 16 rows of a
+//    ds_read_b128 lane group hit 16 distinct 16-byte slots); V as two planes, d 0..31 [64][32] (64-byte pitch: the 4 rows x
+//    64 B of one transposing read are 256 contiguous bytes) and d 32..39 [64][8].
+//  * The pad operands are LDS constants addressed per lane instead of per-tile data: the K fragment lanes of columns 40..47
+//    read a constant [1, 0, ..., 0] (column 40 = 1.0 carries -m_run of the Q fragment into the scores, as in attention.hip),
+//    the V fragment lanes of d = 40..43 read the same constant (row 40 of O^T = sum_kv P: row sums on the matrix pipe),
+//    d >= 44 read zeros.
+//
+// Work decomposition, swapped-operand MFMAs (lane owns a query row), software pipeline (QK^T of tile t+1 | exp / convert of
+// tile t | PV of tile t in one basic block), deferred rescale and the two-segment K/V walk are attention.hip's.
+#include "common.h"
+#include "attn_args.h"
+#include <type_traits>
+
+namespace hallo {
+
+namespace {
+
+constexpr int A40_HD = 40, A40_KVB = 64;
+constexpr int A40_K_TILE = A40_KVB * 80;          // bytes: [64][40] elements, 80-byte pitch
+constexpr int A40_VA_TILE = A40_KVB * 64;         // d 0..31
+constexpr int A40_VB_TILE = A40_KVB * 16;         // d 32..39
+constexpr int A40_OFF_K = 0;
+constexpr int A40_OFF_VA = A40_OFF_K + 2 * A40_K_TILE;       // 10240
+constexpr int A40_OFF_VB = A40_OFF_VA + 2 * A40_VA_TILE;     // 18432
+constexpr int A40_OFF_ONE = A40_OFF_VB + 2 * A40_VB_TILE;    // 20480: 16-byte pattern [1, 0, 0, 0, 0, 0, 0, 0]
+constexpr int A40_ONE_BYTES = 8192;                          // >= largest immediate of a K pad read (stage + t) + 16
+constexpr int A40_OFF_ZERO = A40_OFF_ONE + A40_ONE_BYTES;    // 28672
+constexpr int A40_ZERO_BYTES = 2048;                         // >= largest immediate of a V pad read + 8
+constexpr int A40_LDS = A40_OFF_ZERO + A40_ZERO_BYTES;       // 30720
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  constexpr int HD = A40_HD, KVB = A40_KVB, NT = 2, NKS = 3, NDB = 2;
+  constexpr int L_DB = 1, L_R = 4;               // accumulator slot of O^T row 40 (lanes hi = 0): block 1, row 8 -> r = 4
+
+  // ONE shared object (a second one makes hipcc drain the DMA queue before every LDS read)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A40_LDS];
+  lds_u8* const lds = (lds_u8*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int nwg = p.batch * p.heads * p.nqb;
+  int bid = xcd_remap(blockIdx.x, nwg);
+  const int qb = bid % p.nqb; bid /= p.nqb;
+  const int h = bid % p.heads;
+  const int b = bid / p.heads;
+
+  const T* __restrict__ Qg = reinterpret_cast<const T*>(p.q) + (long)b * p.q_bs + h * HD;
+  const T* __restrict__ K1 = reinterpret_cast<const T*>(p.k1) + (long)b * p.k1_bs + h * HD;
+  const T* __restrict__ V1 = reinterpret_cast<const T*>(p.v1) + (long)b * p.v1_bs + h * HD;
+  const bool use2 = p.k2 != nullptr && p.Lkv2 > 0 && b >= p.kv2_first;
+  const int b2 = use2 ? (p.kv2_mod > 0 ? (b / p.kv2_div) % p.kv2_mod : b / p.kv2_div) : 0;
+  const T* __restrict__ K2 = use2 ? reinterpret_cast<const T*>(p.k2) + (long)b2 * p.k2_bs + h * HD : K1;
+  const T* __restrict__ V2 = use2 ? reinterpret_cast<const T*>(p.v2) + (long)b2 * p.v2_bs + h * HD : V1;
+  T* __restrict__ Og = reinterpret_cast<T*>(p.o) + (long)b * p.o_bs + h * HD;
+
+  // ---- LDS constants ----
+  {
+    V8 one = zero8<T>();
+    one[0] = from_f32<T>(1.0f);
+    for (int i = tid; i < A40_ONE_BYTES / 16; i += 256) *reinterpret_cast<V8*>(smem + A40_OFF_ONE + i * 16) = one;
+    for (int i = tid; i < A40_ZERO_BYTES / 16; i += 256) *reinterpret_cast<V8*>(smem + A40_OFF_ZERO + i * 16) = zero8<T>();
+  }
+
+  // ---- Q fragments (B operand of S^T = K . Q^T): lane holds Q[q0 + l31][ks*16 + hi*8 .. +8]; element 40 (ks = 2, hi = 1,
+  // slot 0) carries -m_run ----
+  const int q0 = qb * 128 + wave * 32;
+  const int qrow = min(q0 + l31, p.Lq - 1);
+  V8 qf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int d = ks * 16 + hi * 8;
+    qf[ks] = (d < HD) ? ld8<T>(Qg + (long)qrow * p.q_rs + d) : zero8<T>();
+  }
+
+  const int nt1 = (p.Lkv1 + KVB - 1) / KVB;
+  const int nt2 = use2 ? (p.Lkv2 + KVB - 1) / KVB : 0;
+  const int nt = nt1 + nt2;
+
+  // ---- loaders: LDS-DMA through buffer descriptors.  A K tile is 5 wave-instructions (320 chunks of 16 B, chunk c = row
+  // c / 5, column chunk c % 5), a V tile 4 (plane A: chunk c = row c / 4, column chunk c % 4) + 1 (plane B: one chunk per
+  // row).  Wave w issues K instructions {w} (+ {4} for w = 0) and V instructions w0: A2, w1: A0 A3, w2: A1, w3: B.  Rows past
+  // the end of a segment (ragged last tile) get an out-of-range offset: the DMA writes zeros.
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+  auto clamp32 = [](long bytes) { return (int)(bytes > 0xFFFFFFFFL ? 0xFFFFFFFFL : (bytes < 0 ? 0 : bytes)); };
+  auto mk_rsrc = [&](const T* base, long rs, int L) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, clamp32(((long)(L - 1) * rs + HD) * 2), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsK1 = mk_rsrc(K1, p.k1_rs, p.Lkv1), rsV1 = mk_rsrc(V1, p.v1_rs, p.Lkv1);
+  const __amdgpu_buffer_rsrc_t rsK2 = mk_rsrc(K2, use2 ? p.k2_rs : p.k1_rs, use2 ? p.Lkv2 : p.Lkv1);
+  const __amdgpu_buffer_rsrc_t rsV2 = mk_rsrc(V2, use2 ? p.v2_rs : p.v1_rs, use2 ? p.Lkv2 : p.Lkv1);
+
+  // tile row / column chunk of this lane in each of its DMA instructions (fixed for the kernel)
+  const int kc0 = wave_u * 64 + lane, kc1 = 256 + lane;                 // K chunks
+  const int krow0 = kc0 / 5, kcol0 = kc0 - 5 * krow0, krow1 = kc1 / 5, kcol1 = kc1 - 5 * krow1;
+  const int va_i0 = (wave_u == 0) ? 2 : (wave_u == 1 ? 0 : 1);          // plane-A instruction of V slot 0 (waves 0..2)
+  const int vc0 = va_i0 * 64 + lane, vc1 = 192 + lane;                  // plane-A chunks (slot 1: instruction 3, wave 1 only)
+  const int vrow0 = (wave_u == 3) ? lane : (vc0 >> 2), vcol0 = (wave_u == 3) ? 4 : (vc0 & 3);
+  const int vrow1 = vc1 >> 2, vcol1 = vc1 & 3;
+  const int k_dst0 = A40_OFF_K + wave_u * 1024, k_dst1 = A40_OFF_K + 4096;
+  const int v_dst0 = (wave_u == 3) ? A40_OFF_VB : A40_OFF_VA + va_i0 * 1024, v_dst1 = A40_OFF_VA + 3072;
+  const int v_stage0 = (wave_u == 3) ? A40_VB_TILE : A40_VA_TILE;       // stage stride of V slot 0
+
+  unsigned offK0, offK1, offV0, offV1;
+  auto set_segment_k = [&](long krs) {
+    offK0 = (unsigned)((krow0 * krs + kcol0 * 8) * 2);
+    offK1 = (unsigned)((krow1 * krs + kcol1 * 8) * 2);
+  };
+  auto set_segment_v = [&](long vrs) {
+    offV0 = (unsigned)((vrow0 * vrs + vcol0 * 8) * 2);
+    offV1 = (unsigned)((vrow1 * vrs + vcol1 * 8) * 2);
+  };
+  set_segment_k(p.k1_rs);
+  set_segment_v(p.v1_rs);
+
+#define A40_DMA(rs, dst, voff, soff) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + (dst)), 16, (int)(voff), (int)(soff), 0, 0)
+
+  auto dma_k = [&](int it) {
+    const bool s2 = it >= nt1;
+    if (it == nt1) set_segment_k(p.k2_rs);     // wave-uniform, once per kernel
+    const long krs = s2 ? p.k2_rs : p.k1_rs;
+    const int L = s2 ? p.Lkv2 : p.Lkv1;
+    const int kv0 = (s2 ? it - nt1 : it) * KVB;
+    const int so = (int)(kv0 * krs * 2);
+    const int st = (it & 1) * A40_K_TILE;
+    unsigned o0 = offK0, o1 = offK1;
+    if (__builtin_expect(kv0 + KVB > L, 0)) {
+      o0 = (kv0 + krow0 < L) ? o0 : OOB;
+      o1 = (kv0 + krow1 < L) ? o1 : OOB;
+    }
+    if (s2) {
+      A40_DMA(rsK2, k_dst0 + st, o0, so);
+      if (wave_u == 0) A40_DMA(rsK2, k_dst1 + st, o1, so);
+    } else {
+      A40_DMA(rsK1, k_dst0 + st, o0, so);
+      if (wave_u == 0) A40_DMA(rsK1, k_dst1 + st, o1, so);
+    }
+  };
+  auto dma_v = [&](int it) {
+    const bool s2 = it >= nt1;
+    if (it == nt1) set_segment_v(p.v2_rs);
+    const long vrs = s2 ? p.v2_rs : p.v1_rs;
+    const int L = s2 ? p.Lkv2 : p.Lkv1;
+    const int kv0 = (s2 ? it - nt1 : it) * KVB;
+    const int so = (int)(kv0 * vrs * 2);
+    const int st0 = (it & 1) * v_stage0, st1 = (it & 1) * A40_VA_TILE;
+    unsigned o0 = offV0, o1 = offV1;
+    if (__builtin_expect(kv0 + KVB > L, 0)) {
+      o0 = (kv0 + vrow0 < L) ? o0 : OOB;
+      o1 = (kv0 + vrow1 < L) ? o1 : OOB;
+    }
+    if (s2) {
+      A40_DMA(rsV2, v_dst0 + st0, o0, so);
+      if (wave_u == 1) A40_DMA(rsV2, v_dst1 + st1, o1, so);
+    } else {
+      A40_DMA(rsV1, v_dst0 + st0, o0, so);
+      if (wave_u == 1) A40_DMA(rsV1, v_dst1 + st1, o1, so);
+    }
+  };
+#undef A40_DMA
+
+  // ---- fragment read addresses (per lane, fixed): everything else is an immediate offset ----
+  // K fragment (A operand of S^T): K[t*32 + l31][ks*16 + hi*8 .. +8]; ks = 2 / hi = 1 (columns 40..47) -> the constant
+  const lds_u8* const kb01 = lds + A40_OFF_K + l31 * 80 + hi * 16;
+  const lds_u8* const kb2 = hi ? lds + A40_OFF_ONE : lds + A40_OFF_K + l31 * 80 + 64;
+  // V fragment (A operand of O^T): transposing read, 16-lane group g = (d half, kv half hi); lane i of the group addresses
+  // row 4*hi + (i >> 2), 4 columns (i & 3)*4 of the group's 16
+  const int gi = lane & 15, gdh = (lane >> 4) & 1;
+  const lds_u8* const vbA = lds + A40_OFF_VA + (4 * hi + (gi >> 2)) * 64 + gdh * 32 + (gi & 3) * 8;
+  const lds_u8* const vbB = gdh ? lds + A40_OFF_ZERO
+                                : ((gi & 3) < 2 ? lds + A40_OFF_VB + (4 * hi + (gi >> 2)) * 16 + (gi & 3) * 8
+                                                : ((gi & 3) == 2 ? lds + A40_OFF_ONE : lds + A40_OFF_ZERO));
+
+  f32x16 oacc[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.0f;
+  float m_run = 0.0f;
+  constexpr float RESCALE_THR = 6.0f;   // log2 units: P <= 64
+  const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+
+  // S^T = K . Q'^T of K stage `stg` (compile-time)
+  auto qk = [&](auto stg_c, f32x16* sc) {
+    constexpr int ST = decltype(stg_c)::value * A40_K_TILE;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      typedef const __attribute__((address_space(3))) V8* ldsv8;
+      const V8 k0 = *(ldsv8)(kb01 + ST + t * 32 * 80);
+      const V8 k1 = *(ldsv8)(kb01 + ST + t * 32 * 80 + 32);
+      const V8 k2 = *(ldsv8)(kb2 + ST + t * 32 * 80);
+      sc[t] = Vec<T>::mfma32(k0, qf[0], zero16);
+      sc[t] = Vec<T>::mfma32(k1, qf[1], sc[t]);
+      sc[t] = Vec<T>::mfma32(k2, qf[2], sc[t]);
+    }
+  };
+  auto tr4 = [&](const lds_u8* ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
+  };
+
+  // ---- pipeline.  hipcc drains the DMA queue (vmcnt(0)) in front of the first transposing read that follows a DMA issue in
+  // program order, so the DMA is issued AFTER the PV reads of an iteration and its wait sits where it is needed anyway: at the
+  // one barrier per tile, which stands between the softmax / QK^T half and the PV half.  Iteration `it`:
+  //   A  softmax statistics of tile it, QK^T of tile it+1 (K stage (it+1)&1: landed before barrier B of iteration it-1),
+  //      the first EXA exponentials
+  //   B  vmcnt(0) + barrier: V(it) and K(it+2), issued at D of iteration it-1, have landed for every wave
+  //   C  remaining exponentials | O^T += V^T . P^T of tile it (V stage it&1)
+  //   D  DMA V(it+1) -> V stage (it+1)&1 (last read in C of it-1) and K(it+3) -> K stage (it+1)&1 (last read in A of it)
+  f32x16 s_a[NT], s_b[NT];
+  if (nt > 0) {
+    dma_k(0);
+    dma_v(0);
+    if (nt > 1) dma_k(1);
+  }
+  __syncthreads();                      // vmcnt(0) + barrier: constants and the first tiles are visible
+  if (nt > 0) qk(std::integral_constant<int, 0>{}, s_a);
+  __syncthreads();                      // every wave has read K(0) before K(2) lands in its stage
+  if (nt > 2) dma_k(2);
+
+  constexpr int EXA = 16;               // exponentials (of 32) issued before the barrier
+  auto tile_step = [&](auto more_c, auto par_c, int it, f32x16* s_cur, f32x16* s_nxt) {
+    constexpr bool MORE = decltype(more_c)::value;      // a tile it+1 exists
+    constexpr int PAR = decltype(par_c)::value;         // it & 1
+
+    const bool s2 = it >= nt1;
+    const int L = s2 ? p.Lkv2 : p.Lkv1;
+    const int kv0 = (s2 ? it - nt1 : it) * KVB;
+    if (__builtin_expect(kv0 + KVB > L, 0)) {
+      asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          s_cur[t][r] = (kv < L) ? s_cur[t][r] : -3.0e38f;
+        }
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(s_cur[t][r], s_cur[t][r + 1]), mx);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // s_cur holds s - m_run (m_run = 0 before the first tile, which always takes this branch); deferred rescale
+    if (__builtin_expect(it == 0 || !__all(mx <= RESCALE_THR), 0)) {
+      asm volatile("" ::: "memory");
+      const float want = m_run + (it == 0 ? mx : fmaxf(mx, 0.0f));
+      const float m_new = to_f32(from_f32<T>(want));          // any reference value works; it must be exact in T
+      const float delta = m_new - m_run;
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m_run = m_new;
+      if (hi) qf[2][0] = from_f32<T>(-m_new);                  // Q'[row][40]
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_cur[t][r] -= delta;
+    }
+
+    // ---- A: QK^T of tile it+1 | first exponentials of tile it ----
+    if (MORE) qk(std::integral_constant<int, 1 - PAR>{}, s_nxt);
+    V8 pf[NT][2];
+#pragma unroll
+    for (int e = 0; e < EXA; ++e)
+      pf[e >> 4][(e >> 3) & 1][e & 7] = from_f32<T>(__builtin_amdgcn_exp2f(s_cur[e >> 4][e & 15]));
+    __syncthreads();        // B
+    // ---- C: remaining exponentials | O^T += V^T . P^T of tile it ----
+#pragma unroll
+    for (int e = EXA; e < 32; ++e)
+      pf[e >> 4][(e >> 3) & 1][e & 7] = from_f32<T>(__builtin_amdgcn_exp2f(s_cur[e >> 4][e & 15]));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int row0 = t * 32 + h2 * 16;       // slots 0..3: kv = row0 + 4*hi + j; slots 4..7: kv = row0 + 8 + 4*hi + j
+        {
+          const s16x4 lo = tr4(vbA + PAR * A40_VA_TILE + row0 * 64);
+          const s16x4 hi4 = tr4(vbA + PAR * A40_VA_TILE + (row0 + 8) * 64);
+          const s16x8 v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+          oacc[0] = Vec<T>::mfma32(__builtin_bit_cast(V8, v), pf[t][h2], oacc[0]);
+        }
+        {
+          const s16x4 lo = tr4(vbB + PAR * A40_VB_TILE + row0 * 16);
+          const s16x4 hi4 = tr4(vbB + PAR * A40_VB_TILE + (row0 + 8) * 16);
+          const s16x8 v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+          oacc[1] = Vec<T>::mfma32(__builtin_bit_cast(V8, v), pf[t][h2], oacc[1]);
+        }
+      }
+    }
+    // ---- D ----
+    if (MORE) dma_v(it + 1);
+    if (it + 3 < nt) dma_k(it + 3);
+  };
+  {
+    using TT = std::true_type;
+    using FF = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int it = 0;
+    for (; it + 2 < nt; it += 2) {     // two tiles per trip: score registers and LDS stages alternate by name
+      tile_step(TT{}, P0{}, it, s_a, s_b);
+      tile_step(TT{}, P1{}, it + 1, s_b, s_a);
+    }
+    if (it + 2 == nt) {
+      tile_step(TT{}, P0{}, it, s_a, s_b);
+      tile_step(FF{}, P1{}, it + 1, s_b, s_a);
+    } else if (it + 1 == nt) {
+      tile_step(FF{}, P0{}, it, s_a, s_b);
+    }
+  }
+
+  // ---- normalise and store: lane owns row q0+l31, d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
+  const float l_tot = __shfl(oacc[L_DB][L_R], l31, 64);       // row 40 of O^T lives in the hi = 0 lane of column q
+  float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  if (p.o_rowscale && q0 + l31 < p.Lq) inv *= p.o_rowscale[(long)(h / p.rs_hdiv) * p.rs_stride + (long)b * p.Lq + q0 + l31];
+  if (q0 + l31 < p.Lq) {
+    T* orow = Og + (long)(q0 + l31) * p.o_rs;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + 8 * g + 4 * hi;
+        if (d0 < HD) {
+          V4 w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = from_f32<T>(oacc[db][g * 4 + j] * inv);
+          *reinterpret_cast<V4*>(orow + d0) = w;
+        }
+      }
+    }
+  }
+}
+
+int launch_attn40(const AttnArgs& a, int dtype, hipStream_t st) {
+  dim3 grid(a.batch * a.heads * a.nqb), block(256);
+  if (dtype == DT_F16) hipLaunchKernelGGL((attn40_kernel<_Float16>), grid, block, 0, st, a);
+  else if (dtype == DT_BF16) hipLaunchKernelGGL((attn40_kernel<__bf16>), grid, block, 0, st, a);
+  else return -22;
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace hallo

@@ -1,0 +1,23 @@
+// Kernel argument block shared by the attention kernels (attention.hip: generic head dims; attention40.hip: the
+// LDS-DMA / transposing-read kernel for head dim 40).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hallo {
+
+struct AttnArgs {
+  const void* q; const void* k1; const void* v1; const void* k2; const void* v2; void* o;
+  int batch, heads, Lq, Lkv1, Lkv2;
+  long q_bs, q_rs, k1_bs, k1_rs, v1_bs, v1_rs, k2_bs, k2_rs, v2_bs, v2_rs, o_bs, o_rs;
+  int kv2_div, kv2_mod, kv2_first;
+  float scale_log2e;
+  int nqb;  // query blocks per (batch, head)
+  const float* o_rowscale;   // optional fp32 output row scale: o[b, q, head h] *= o_rowscale[(h / rs_hdiv) * rs_stride + b * Lq + q]
+  int rs_hdiv;
+  long rs_stride;
+};
+
+// attention40.hip: head dim 40, pre-scaled q.  Returns 0 or a negative status like the other launchers.
+int launch_attn40(const AttnArgs& a, int dtype, hipStream_t st);
+
+}  // namespace hallo

@@ -168,7 +168,9 @@ def test_vae_mid_attention_full(dtype, report):
             p.copy_(p.to(dtype).float())
     sd = {k: v.clone() for k, v in att.state_dict().items()}
     att.to(device=_dev(), dtype=dtype)
-    att.prepare()
+    for m in att.modules():
+        if hasattr(m, "_prepare"):
+            m._prepare()
     x = _rand((n, L, Cd), dtype, g)
     out = att.run(x)
     xf = x.float()
