@@ -675,7 +675,7 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
 
 extern "C" int hallo_set_option_attn(const char* name, int value) {
   if (name && !strcmp(name, "temporal_mfma")) { if (value < 0 || value > 1) return -22; g_temporal_mfma = value; return 0; }
-  if (name && !strcmp(name, "attn40")) { if (value < 0 || value > 1) return -22; g_attn40 = value; return 0; }
+  if (name && !strcmp(name, "attn40")) { if (value < 0 || value > 8) return -22; g_attn40 = value; set_attn40_variant(value); return 0; }
   return -22;
 }
 

@@ -48,7 +48,8 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 }  // namespace
 
-template <typename T>
+// EXA = exponentials (of 32 per tile) issued before the barrier; PRIO = raise the wave priority around the MFMA clusters
+template <typename T, int EXA, int PRIO>
 __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
@@ -242,7 +243,6 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   __syncthreads();                      // every wave has read K(0) before K(2) lands in its stage
   if (nt > 2) dma_k(2);
 
-  constexpr int EXA = 16;               // exponentials (of 32) issued before the barrier
   auto tile_step = [&](auto more_c, auto par_c, int it, f32x16* s_cur, f32x16* s_nxt) {
     constexpr bool MORE = decltype(more_c)::value;      // a tile it+1 exists
     constexpr int PAR = decltype(par_c)::value;         // it & 1
@@ -265,7 +265,10 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(s_cur[t][r], s_cur[t][r + 1]), mx);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    {   // the partner lane (lane ^ 32) holds the other half of the row: one VALU half-swap instead of an LDS round trip
+      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
+      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    }
     // s_cur holds s - m_run (m_run = 0 before the first tile, which always takes this branch); deferred rescale
     if (__builtin_expect(it == 0 || !__all(mx <= RESCALE_THR), 0)) {
       asm volatile("" ::: "memory");
@@ -286,7 +289,9 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
     }
 
     // ---- A: QK^T of tile it+1 | first exponentials of tile it ----
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
     if (MORE) qk(std::integral_constant<int, 1 - PAR>{}, s_nxt);
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
     V8 pf[NT][2];
 #pragma unroll
     for (int e = 0; e < EXA; ++e)
@@ -296,6 +301,7 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
 #pragma unroll
     for (int e = EXA; e < 32; ++e)
       pf[e >> 4][(e >> 3) & 1][e & 7] = from_f32<T>(__builtin_amdgcn_exp2f(s_cur[e >> 4][e & 15]));
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -315,6 +321,7 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
         }
       }
     }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
     // ---- D ----
     if (MORE) dma_v(it + 1);
     if (it + 3 < nt) dma_k(it + 3);
@@ -359,10 +366,25 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   }
 }
 
+static int g_attn40_variant = 1;     // hallo_set_option("attn40", v): 0 = attention.hip, 1.. = schedule variants of this kernel (A/B)
+
+void set_attn40_variant(int v) { g_attn40_variant = v; }
+
+template <typename T>
+static void launch_variant(const AttnArgs& a, dim3 grid, hipStream_t st) {
+  switch (g_attn40_variant) {
+    case 2: hipLaunchKernelGGL((attn40_kernel<T, 0, 0>), grid, dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((attn40_kernel<T, 32, 0>), grid, dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((attn40_kernel<T, 16, 1>), grid, dim3(256), 0, st, a); break;
+    case 5: hipLaunchKernelGGL((attn40_kernel<T, 8, 0>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((attn40_kernel<T, 16, 0>), grid, dim3(256), 0, st, a); break;
+  }
+}
+
 int launch_attn40(const AttnArgs& a, int dtype, hipStream_t st) {
-  dim3 grid(a.batch * a.heads * a.nqb), block(256);
-  if (dtype == DT_F16) hipLaunchKernelGGL((attn40_kernel<_Float16>), grid, block, 0, st, a);
-  else if (dtype == DT_BF16) hipLaunchKernelGGL((attn40_kernel<__bf16>), grid, block, 0, st, a);
+  dim3 grid(a.batch * a.heads * a.nqb);
+  if (dtype == DT_F16) launch_variant<_Float16>(a, grid, st);
+  else if (dtype == DT_BF16) launch_variant<__bf16>(a, grid, st);
   else return -22;
   HALLO_CHECK_LAUNCH();
   return 0;

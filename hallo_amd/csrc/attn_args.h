@@ -19,5 +19,6 @@ struct AttnArgs {
 
 // attention40.hip: head dim 40, pre-scaled q.  Returns 0 or a negative status like the other launchers.
 int launch_attn40(const AttnArgs& a, int dtype, hipStream_t st);
+void set_attn40_variant(int v);
 
 }  // namespace hallo

@@ -41,4 +41,9 @@ struct GemmArgs {
 // (gemm / geglu only, no split-K).
 template <typename T> void launch_gemm3(const GemmArgs& a, int mode, int tm, int batch, hipStream_t st, bool persist);
 
+// gemm_rs.hip: row-stationary kernel for K = 320 / 640 (A rows of a workgroup in registers, LayerNorm statistics computed
+// from them, W streamed through an LDS ring).  gemm_rs_eligible() is the routing rule of launch_gemm().
+bool gemm_rs_eligible(const GemmArgs& a, bool conv, bool geglu, int batch);
+template <typename T> int launch_gemm_rs(const GemmArgs& a, bool geglu, hipStream_t st);
+
 }  // namespace hallo

@@ -225,7 +225,7 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
 
         x2 = x.view(n * L, D)
         q3 = ops.gemm(x2, self.w_q3_ln, self.b_q3_ln, alpha=ops.q_scale(self.attn2_0.dim_head), ln_colsum=self.g_q3_ln,
-                      ln_eps=self.norm2.eps, ln_stats=ops.row_stats(x2, self.norm2.eps)).view(n, L, 3 * D)
+                      ln_eps=self.norm2.eps, ln_stats=ops.ln_stats(x2, 3 * D, self.norm2.eps)).view(n, L, 3 * D)
         # three branches x heads as one attention launch; output rows pre-scaled by motion_scale[i] * mask_i
         # (attention.py:853-903) and written straight into the fused GEMM's A operand
         ops.attention(q3, kv3[:, :, :3 * D], kv3[:, :, 3 * D:], 3 * self.attn2_0.heads,

@@ -240,7 +240,9 @@ class Attention(nn.Module):
         N, L, Cd = x.shape
         x2 = x.view(N * L, Cd)
         y = ops.gemm(x2, self._ln_w, self._ln_b, lead_cols=self.inner, lead_alpha=ops.q_scale(self.dim_head),
-                     ln_colsum=self._ln_g, ln_eps=self._ln_eps, ln_stats=ops.row_stats(x2, self._ln_eps), bias2=bias2,
+                     ln_colsum=self._ln_g, ln_eps=self._ln_eps,
+                     ln_stats=ops.ln_stats(x2, 3 * self.inner, self._ln_eps, bias2_rows_per_group=bias2_rows_per_group if bias2 is not None else 0,
+                                           lead_cols=self.inner), bias2=bias2,
                      bias2_rows_per_group=bias2_rows_per_group).view(N, L, 3 * self.inner)
         i = self.inner
         return y, y[:, :, :i], y[:, :, i:2 * i], y[:, :, 2 * i:]
@@ -286,7 +288,7 @@ class FeedForward(nn.Module):
         N, L, Cd = x.shape
         x2 = x.view(N * L, Cd)
         h = ops.gemm(x2, self._ln_w, self._ln_b, geglu=True, ln_colsum=self._ln_g, ln_eps=self._ln_eps,
-                     ln_stats=ops.row_stats(x2, self._ln_eps))
+                     ln_stats=ops.ln_stats(x2, self._ln_w.shape[0] // 2, self._ln_eps, geglu=True))
         y = self.net[2].run(h, residual=x.view(N * L, Cd))
         return y.view(N, L, Cd)
 

@@ -75,7 +75,8 @@ class TemporalTransformerBlock(nn.Module):
             wf, gcs, bf = self._ln[i]
             # row r = (b*frames + f)*L + pixel -> bias2 row r / L
             h2 = h.view(n * L, Cd)
-            qkv = ops.gemm(h2, wf, bf, ln_colsum=gcs, ln_eps=norm.eps, ln_stats=ops.row_stats(h2, norm.eps),
+            qkv = ops.gemm(h2, wf, bf, ln_colsum=gcs, ln_eps=norm.eps,
+                           ln_stats=ops.ln_stats(h2, 3 * Cd, norm.eps, bias2_rows_per_group=L),
                            bias2=self._pe_rows(i, attn, batch, frames), bias2_rows_per_group=L).view(n, L, 3 * Cd)
             a = ops.temporal_attention(qkv, batch, frames, L, Cd, attn.heads)
             h = attn.out(a, residual=h)

@@ -417,6 +417,16 @@ def row_stats(x2d, eps=1e-5):
     return st
 
 
+def ln_stats(x2d, n_out, eps=1e-5, *, geglu=False, bias2_rows_per_group=0, lead_cols=0):
+    """`ln_stats` argument for a LayerNorm-fused gemm(x2d, w[n_out(, x2), K], ...): None when the library's row-stationary
+    kernel will take the problem and derive mean / rstd from the A rows it keeps in registers (hallo_gemm_fuses_row_stats),
+    else the statistics from hallo_row_stats."""
+    M, K = x2d.shape
+    if x2d.is_contiguous() and _l.load().hallo_gemm_fuses_row_stats(M, n_out, K, 1 if geglu else 0, bias2_rows_per_group, lead_cols):
+        return None
+    return row_stats(x2d, eps)
+
+
 _w2v_ws = {}
 
 

@@ -241,6 +241,13 @@ int hallo_cfg_ddim_step(const void* model_out, int64_t ldm, float* latents, void
  * (ln_colsum / ln_stats).  C % 8 == 0, C <= 1536. */
 int hallo_row_stats(const void* x, float* stats, int64_t rows, int C, float eps, int dtype, void* stream);
 
+/* hallo_gemm_fuses_row_stats (ABI v4): 1 when hallo_gemm, called with ln_colsum set and ln_stats = NULL on a problem of
+ * this shape (contiguous A / W, dtype output, bias2 with `bias2_rows_per_group` rows per group or 0, `lead_cols`), takes the
+ * row-stationary kernel (csrc/gemm_rs.hip: K = 320 / 640, the A rows of a workgroup held in registers) that derives the
+ * LayerNorm statistics from its resident A rows -- the caller can then skip hallo_row_stats.  0: pass ln_stats (or accept
+ * the in-K-loop statistics of the tiled kernel).  Pure function of its arguments and of hallo_set_option("gemm_rs"). */
+int hallo_gemm_fuses_row_stats(int M, int N, int K, int geglu, int bias2_rows_per_group, int lead_cols);
+
 /* ------------------------------------------------------------------------------------------
  * hallo_face_xattn: y = x + to_out(SDPA(to_q(LayerNorm(x)), K_face, V_face)) for a cross-attention over H*T = 32
  * (head, token) pairs -- norm2 + attn2 + residual of the spatial transformer block

@@ -182,3 +182,98 @@ def test_vae_mid_attention_full(dtype, report):
     o = ops_ref.sdpa(q, k, v, 1)
     ref = o @ f("to_out.0.weight").t() + f("to_out.0.bias") + xf
     _check("vae_mid_attention[2,4096,512]", out, ref, dtype, report)
+
+
+# --------------------------------------------------------------------------------------------
+# gemm_rs.hip: the row-stationary kernel for K = 320 / 640 (A rows in registers, LayerNorm statistics computed in-kernel)
+def _took_rs(ops):
+    return (ops.get_option("last_gemm_kernel") % 1000) // 100 == 4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(65536, 960, 320), (16384, 1920, 640), (73728, 960, 320), (8192 + 40, 320, 320),
+                                   (16384 + 8, 640, 640)])
+def test_gemm_rs_layernorm_qkv(dtype, M, N, K, report):
+    """Fused q|k|v projection with norm folded in, no statistics handed over: the library takes the row-stationary kernel,
+    which derives mean / rstd from its resident A rows; lead-column scale on the q third, a per-frame bias2 (the motion
+    module's PE @ W^T rows) in one case, a partial last N tile (960 = 7.5 x 128), M not a multiple of the row block."""
+    from hallo_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _rand((M, K), dtype, g) * 1.3 + 0.4
+    gamma = (1.0 + 0.1 * torch.randn((K,), generator=g)).to(dtype).to(_dev())
+    beta = _rand((K,), dtype, g, 0.1)
+    w = _rand((N, K), dtype, g, K ** -0.5)
+    b = _rand((N,), dtype, g, 0.1)
+    wf, cs, bf = ops.fold_layernorm(gamma, beta, w, b)
+    lead = N // 3
+    rpg = 4096 if M % 4096 == 0 else 0
+    b2 = _rand((M // 4096, N), dtype, g) if rpg else None
+    assert ops.ln_stats(x, N, 1e-5, bias2_rows_per_group=rpg, lead_cols=lead) is None        # the library fuses the statistics
+    out = ops.gemm(x, wf, bf, ln_colsum=cs, ln_eps=1e-5, lead_cols=lead, lead_alpha=0.25, bias2=b2, bias2_rows_per_group=rpg)
+    assert _took_rs(ops), ops.get_option("last_gemm_kernel")
+    nh = torch.nn.functional.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5)
+    ref = nh @ w.float().t() + b.float()
+    if rpg:
+        ref = ref + b2.float().repeat_interleave(rpg, 0)
+    ref[:, :lead] *= 0.25
+    _check(f"gemm_rs_ln[{M},{N},{K}]", out, ref, dtype, report)
+    ops.set_option("gemm_rs", 0)
+    try:
+        old = ops.gemm(x, wf, bf, ln_colsum=cs, ln_eps=1e-5, lead_cols=lead, lead_alpha=0.25, bias2=b2, bias2_rows_per_group=rpg,
+                       ln_stats=ops.row_stats(x, 1e-5))
+        assert not _took_rs(ops)
+    finally:
+        ops.set_option("gemm_rs", 1)
+    _check(f"gemm_rs_ln_vs_tiled[{M},{N},{K}]", out, old.float(), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Cd", [(65536, 320), (16384, 640), (73728, 320), (8192 + 24, 320)])
+def test_gemm_rs_geglu(dtype, M, Cd, report):
+    """FeedForward net.0 with norm3 folded in on the row-stationary kernel (value / gate rows of W in one chunk)."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(5 * M + Cd)
+    x = _rand((M, Cd), dtype, g) * 1.2 - 0.3
+    gamma = (1.0 + 0.1 * torch.randn((Cd,), generator=g)).to(dtype).to(_dev())
+    beta = _rand((Cd,), dtype, g, 0.1)
+    w = _rand((8 * Cd, Cd), dtype, g, Cd ** -0.5)
+    b = _rand((8 * Cd,), dtype, g, 0.1)
+    wf, cs, bf = ops.fold_layernorm(gamma, beta, w, b)
+    out = ops.gemm(x, wf, bf, geglu=True, ln_colsum=cs, ln_eps=1e-5, ln_stats=ops.ln_stats(x, 4 * Cd, 1e-5, geglu=True))
+    assert _took_rs(ops), ops.get_option("last_gemm_kernel")
+    nh = torch.nn.functional.layer_norm(x.float(), (Cd,), gamma.float(), beta.float(), 1e-5)
+    _check(f"gemm_rs_geglu_ln[{M},{Cd}]", out, ops_ref.geglu(nh, w, b), dtype, report)
+    out = ops.gemm(x, w, b, geglu=True)                                      # without LayerNorm
+    assert _took_rs(ops)
+    _check(f"gemm_rs_geglu[{M},{Cd}]", out, ops_ref.geglu(x, w, b), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_rs_plain_and_fallbacks(dtype, report):
+    """Plain projection (bias, alpha) on the row-stationary kernel; shapes / epilogues it does not implement stay on the
+    tiled kernels (residual, small M, K other than 320 / 640, statistics handed over)."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 65536, 320, 320
+    a = _rand((M, K), dtype, g)
+    w = _rand((N, K), dtype, g, K ** -0.5)
+    b = _rand((N,), dtype, g)
+    out = ops.gemm(a, w, b, alpha=0.5)
+    assert _took_rs(ops)
+    _check("gemm_rs_plain", out, 0.5 * ops_ref.linear(a, w, b), dtype, report)
+    wide = _rand((M, 3 * K), dtype, g)                                        # strided A (column slice of a wider buffer)
+    out = ops.gemm(wide[:, K:2 * K], w, b)
+    assert _took_rs(ops)
+    _check("gemm_rs_strided_a", out, ops_ref.linear(wide[:, K:2 * K], w, b), dtype, report)
+    res = _rand((M, N), dtype, g)
+    ops.gemm(a, w, b, residual=res)
+    assert not _took_rs(ops)
+    ops.gemm(a[:1024], w, b)
+    assert not _took_rs(ops)
+    assert ops.ln_stats(a[:1024], N, 1e-5) is not None
+    a2 = _rand((M, 1280), dtype, g)
+    w2 = _rand((N, 1280), dtype, g, 1280 ** -0.5)
+    ops.gemm(a2, w2, b)
+    assert not _took_rs(ops)

@@ -49,18 +49,19 @@ def main():
                 ref = ops_ref.reference_self_attention(qf, k1[:2], v1[:2], kw["k2"], kw["v2"], H, Fr, 0)
             else:
                 ref = ops_ref.sdpa(qf, k1[:2], v1[:2], H)
-            times = {0: [], 1: []}
+            VARS = tuple(int(v) for v in os.environ.get("AB_VARIANTS", "0,1").split(","))
+            times = {v: [] for v in VARS}
             errs = {}
-            for v in (0, 1):
+            for v in VARS:
                 ops.set_option("attn40", v)
                 o = run()
                 errs[v] = ((o[:2].float() - ref).norm() / ref.norm()).item()
                 ev_time(run, 3)
             for _ in range(rounds):
-                for v in (0, 1):
+                for v in VARS:
                     ops.set_option("attn40", v)
                     times[v].append(ev_time(run, 10))
-            for v in (0, 1):
+            for v in VARS:
                 ts = sorted(times[v])
                 rec = dict(shape=name, dtype=str(dtype), attn40=v, ms_median=ts[len(ts) // 2], ms_min=ts[0],
                            tflops_median=flop / ts[len(ts) // 2] / 1e9, rel_l2_vs_fp32=errs[v])
