@@ -1025,5 +1025,6 @@ extern "C" int hallo_set_option(const char* name, int value) {
   if (!strcmp(name, "conv_fast")) { if (value < 0 || value > 1) return -22; g_conv_fast = value; return 0; }
   if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }
   if (!strcmp(name, "gemm_rs")) { if (value < 0 || value > 1) return -22; g_gemm_rs = value; return 0; }
+  if (!strcmp(name, "gemm_rs_dbg")) { set_gemm_rs_dbg(value); return 0; }
   return hallo_set_option_norm(name, value);
 }

@@ -45,5 +45,6 @@ template <typename T> void launch_gemm3(const GemmArgs& a, int mode, int tm, int
 // from them, W streamed through an LDS ring).  gemm_rs_eligible() is the routing rule of launch_gemm().
 bool gemm_rs_eligible(const GemmArgs& a, bool conv, bool geglu, int batch);
 template <typename T> int launch_gemm_rs(const GemmArgs& a, bool geglu, hipStream_t st);
+void set_gemm_rs_dbg(int v);
 
 }  // namespace hallo

@@ -32,7 +32,7 @@ def main():
     out = []
     cases = [("qkv L0", 65536, 960, 320, False, True), ("qkv motion L0", 73728, 960, 320, False, True),
              ("geglu L0", 65536, 1280, 320, True, True), ("geglu motion L0", 73728, 1280, 320, True, True),
-             ("qkv L1", 16384, 1920, 640, False, True), ("geglu L1", 16384, 2560, 640, True, True),
+             ("qkv L1", 16384, 1920, 640, False, True), ("qkv K=640 65536 rows", 65536, 1920, 640, False, True),
              ("proj_in L0 (plain)", 65536, 320, 320, False, False)]
     for name, M, N, K, geglu, ln in cases:
         x = rnd(M, K) + 0.3
