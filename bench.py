@@ -69,9 +69,14 @@ class OpProfiler:
                 return "gemm_kernel<%s,%s,%s>" % (dt, "true" if mode == 1 else "false", "true" if mode == 2 else "false")
             if kern == 2:
                 return "gemm2_kernel<%s,%d,%d,%d>" % (dt, mode, sub, lnf)
+            if kern == 4:      # row-stationary kernel (csrc/gemm_rs.hip): <T, K/16, W blocks per chunk, geglu, layernorm>
+                return "gemm_rs_kernel<%s,%d,%d,%s,%s>" % (dt, 20 if sub == 1 else 40, 4 if sub == 1 else 2,
+                                                           "true" if mode == 2 else "false", "true" if lnf else "false")
             return "gemm3_kernel<%s,%d,%d,%s>" % (dt, mode, sub & 3, "true" if sub & 4 else "false")
         if name == "attention":
             hd = a[0].shape[-1] // a[3]
+            if hd == 40 and k.get("q_prescaled") and ops.get_option("attn40") > 0:
+                return "attn40_kernel<%s,16,0>" % dt          # csrc/attention40.hip (LDS-DMA K/V, transposing V reads)
             return "attn_kernel<%s,%d,%s>" % (dt, hd, "true" if k.get("q_prescaled") else "false")
         return name
 
@@ -151,15 +156,26 @@ class OpProfiler:
         fam = {}
         self.by_shape = {}
         self.by_symbol = {}
+        self.attn_families = {}
         for name, s, e, fl, by, shp, sym in self.records:
             ms_ = s.elapsed_time(e)
-            for table, key in ((self.by_shape, (name, shp)), (fam, name), (self.by_symbol, sym)):
+            tables = [(self.by_shape, (name, shp)), (fam, name), (self.by_symbol, sym)]
+            if name == "attention":        # shp = (q shape, k1 shape, v1 shape[, ("k2", shape)]): classify by the K/V length
+                lkv = shp[1][1]
+                af = "spatial self-attention (K/V >= 256 tokens, compute-bound)" if lkv >= 256 else \
+                     "token cross-attention (K/V = 4 face / 3 x 32 audio tokens, HBM-bound)"
+                tables.append((self.attn_families, af))
+            elif name == "temporal_attention":
+                tables.append((self.attn_families, "temporal attention (F' = 18 frames per pixel, HBM-bound)"))
+            elif name == "face_xattn":
+                tables.append((self.attn_families, "fused face cross-attention (norm2 + attn2 + residual, HBM-bound)"))
+            for table, key in tables:
                 d = table.setdefault(key, dict(ms=0.0, flop=0.0, bytes=0.0, launches=0))
                 d["ms"] += ms_
                 d["flop"] += fl
                 d["bytes"] += by
                 d["launches"] += 1
-        for table in (fam, self.by_symbol):
+        for table in (fam, self.by_symbol, self.attn_families):
             for d in table.values():
                 d["tflops"] = d["flop"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
                 d["gbs"] = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
@@ -427,22 +443,25 @@ def main():
         out["kernel_ms_per_clip"] = round(tot_ms, 1)
         out["algorithmic_tflop_per_clip"] = round(tot_flop / 1e12, 1)
         # roofline of the dominant kernel SYMBOL (the name rocprofv3 --kernel-trace --stats reports; the committed summary
-        # profiles/r1_bench_kernel_stats.csv is of this same command).  achieved = algorithmic flop (or bytes) of that
+        # profiles/r2_bench_kernel_stats.csv is of this same command).  achieved = algorithmic flop (or bytes) of that
         # symbol's launches / their summed duration, both from events on the launch stream in this run.
         out["kernel_symbols"] = {k: {"ms": round(d["ms"], 2), "launches": d["launches"], "tflops": round(d["tflops"], 1),
                                      "gbs": round(d["gbs"], 1), "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1)}
                                  for k, d in sorted(prof.by_symbol.items(), key=lambda kv: -kv[1]["ms"])[:12]}
         name, d = max(prof.by_symbol.items(), key=lambda kv: kv[1]["ms"])
+        # HBM traffic of the dominant symbol from separate rocprofv3 --pmc passes (tools/pmc_passes.sh + tools/
+        # pmc_traffic_like_for_like.py -> profiles/r2_pmc_traffic.json): FETCH_SIZE / WRITE_SIZE of single launches next to the
+        # algorithmic bytes of THOSE launches, per launch shape.  It is a committed measurement of this binary's kernel, not
+        # something this run produced (the counter passes cannot run inside a timed bench).
         traffic = None
-        try:    # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py), if committed
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
             t = tj.get(name.split("<")[0])
             if t:
-                wr = t.get("write_bytes_per_launch")
-                traffic = {"fetch_bytes_per_launch": round(t["fetch_bytes_per_launch"]),
-                           "write_bytes_per_launch": round(wr) if wr is not None else None,
-                           "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
-                           "source": t.get("note") or tj.get("_source", "profiles/r1_pmc_traffic.json")}
+                traffic = {"per_launch_shape": [{k: (round(v) if isinstance(v, float) and v > 1000 else v) for k, v in e.items()} for e in t],
+                           "algorithmic_bytes_per_launch_this_run": round(d["bytes"] / d["launches"]),
+                           "source": "profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over "
+                                     "tools/pmc_attn.py; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md)"}
         except Exception:
             pass
         # bound by arithmetic intensity against the machine balance (2500 TFLOP/s / 8 TB/s = 312 flop/B): the K = 320
@@ -462,6 +481,13 @@ def main():
             a = fam["attention"]
             out["attention"] = {"hbm_gbs": round(a["gbs"], 1), "hbm_frac": round(a["gbs"] / PEAK_HBM_GBS, 4),
                                 "tflops": round(a["tflops"], 1), "mfma_frac": round(a["tflops"] / PEAK_BF16_TFLOPS, 4)}
+        # north_star's "fraction of the HBM roofline in attention", per attention family: the L0 / L1 spatial self-attention is
+        # compute-bound by construction (2700 / 680 flop per byte), the other three families are HBM-bound kernels
+        out["attention_families"] = {
+            k: {"ms": round(v["ms"], 2), "launches": v["launches"], "hbm_gbs": round(v["gbs"], 1),
+                "hbm_frac": round(v["gbs"] / PEAK_HBM_GBS, 4), "tflops": round(v["tflops"], 1),
+                "mfma_frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4)}
+            for k, v in sorted(prof.attn_families.items(), key=lambda kv: -kv[1]["ms"])}
         out["end_to_end_mfma_frac"] = round(tot_flop / 1e12 / (elapsed / args.steps) / PEAK_BF16_TFLOPS, 4)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:

@@ -666,10 +666,17 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
   a.rs_hdiv = d->o_rowscale_head_div > 0 ? d->o_rowscale_head_div : d->heads;
   a.rs_stride = d->o_rowscale_stride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (g_attn40 && d->head_dim == 40 && d->q_prescaled != 0 && (d->dtype == DT_F16 || d->dtype == DT_BF16))
+  if (g_attn40 && d->head_dim == 40 && d->q_prescaled != 0 && (d->dtype == DT_F16 || d->dtype == DT_BF16) &&
+      !(d->o_rs & 7) && !(d->o_bs & 7) && !(reinterpret_cast<uintptr_t>(d->o) & 15))          // 16-byte output stores
     return launch_attn40(a, d->dtype, st);          // attention40.hip: LDS-DMA staging + transposing V reads
   if (d->dtype == DT_F16) return launch_attn<_Float16>(a, d->head_dim, d->q_prescaled != 0, st);
   if (d->dtype == DT_BF16) return launch_attn<__bf16>(a, d->head_dim, d->q_prescaled != 0, st);
+  return -22;
+}
+
+extern "C" int hallo_get_option_attn(const char* name) {
+  if (name && !strcmp(name, "attn40")) return g_attn40;
+  if (name && !strcmp(name, "temporal_mfma")) return g_temporal_mfma;
   return -22;
 }
 

@@ -66,6 +66,10 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
 
   const int nwg = p.batch * p.heads * p.nqb;
   int bid = xcd_remap(blockIdx.x, nwg);
+  // block order: query block fastest, then head, then frame -- the ~96 workgroups an XCD runs at a time cover three
+  // neighbouring HEADS of one frame, whose 80-byte K / V row slices share 128-byte lines.  (Frame-fastest order, which lets
+  // three frames share the reference bank's K/V of a head, was measured and is worse: the lines are then used by one head
+  // only -- FETCH_SIZE 2.4x / 3.1x the algorithmic reads instead of 1.15x / 2.6x, and the kernel 7 % slower.)
   const int qb = bid % p.nqb; bid /= p.nqb;
   const int h = bid % p.heads;
   const int b = bid / p.heads;
@@ -348,20 +352,30 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   const float l_tot = __shfl(oacc[L_DB][L_R], l31, 64);       // row 40 of O^T lives in the hi = 0 lane of column q
   float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
   if (p.o_rowscale && q0 + l31 < p.Lq) inv *= p.o_rowscale[(long)(h / p.rs_hdiv) * p.rs_stride + (long)b * p.Lq + q0 + l31];
-  if (q0 + l31 < p.Lq) {
-    T* orow = Og + (long)(q0 + l31) * p.o_rs;
+  {
+    // pack to T; pairs of 4-column groups are merged with a half swap (v_permlane32_swap) so that every lane stores 16
+    // contiguous bytes: the 8-byte stores of the first version cost 1.4x the output bytes in WRITE_SIZE (partial sectors)
+    T* orow = Og + (long)min(q0 + l31, p.Lq - 1) * p.o_rs;
+    const bool live = q0 + l31 < p.Lq;
+    unsigned pk[5][2];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db) {
+    for (int g = 0; g < 5; ++g) {
+      V4 w;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = db * 32 + 8 * g + 4 * hi;
-        if (d0 < HD) {
-          V4 w;
+      for (int j = 0; j < 4; ++j) w[j] = from_f32<T>(oacc[g >> 2][(g & 3) * 4 + j] * inv);     // d = 8g + 4hi + j
+      const uint2 u = __builtin_bit_cast(uint2, w);
+      pk[g][0] = u.x; pk[g][1] = u.y;
+    }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) w[j] = from_f32<T>(oacc[db][g * 4 + j] * inv);
-          *reinterpret_cast<V4*>(orow + d0) = w;
-        }
-      }
+    for (int g = 0; g < 4; g += 2) {     // lanes hi = 0: d 8g .. 8g+7, lanes hi = 1: d 8g+8 .. 8g+15
+      const auto x = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+      const auto y = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+      if (live) *reinterpret_cast<uint4*>(orow + 8 * g + 8 * hi) = make_uint4(x[0], y[0], x[1], y[1]);
+    }
+    {                                    // d 32 .. 39: lanes hi = 0 collect the partner's half and store alone
+      const auto x = __builtin_amdgcn_permlane32_swap(pk[4][0], pk[4][0], false, false);
+      const auto y = __builtin_amdgcn_permlane32_swap(pk[4][1], pk[4][1], false, false);
+      if (live && !hi) *reinterpret_cast<uint4*>(orow + 32) = make_uint4(x[0], y[0], x[1], y[1]);
     }
   }
 }

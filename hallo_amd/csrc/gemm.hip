@@ -1008,6 +1008,8 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
 
 extern "C" int hallo_set_option_norm(const char* name, int value);   // norm_elementwise.hip
 
+extern "C" int hallo_get_option_attn(const char* name);   // attention.hip
+
 extern "C" int hallo_get_option(const char* name) {
   if (!name) return -22;
   if (!strcmp(name, "gemm_variant")) return g_gemm_variant;
@@ -1015,7 +1017,7 @@ extern "C" int hallo_get_option(const char* name) {
   if (!strcmp(name, "v3_min_tiles")) return g_v3_min_tiles;
   if (!strcmp(name, "last_gemm_kernel")) return g_last_kernel;
   if (!strcmp(name, "gemm_rs")) return g_gemm_rs;
-  return -22;
+  return hallo_get_option_attn(name);
 }
 
 extern "C" int hallo_set_option(const char* name, int value) {
