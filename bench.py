@@ -313,6 +313,13 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B: hallo_set_option('gemm_variant', v) (default: library auto)")
     ap.add_argument("--shape-breakdown", action="store_true", help="write gpurun_out/shape_breakdown.json (per op x shape times)")
+    ap.add_argument("--fp8-proj", action="store_true",
+                    help="BASELINE.json configs[4]'s projection variant: q|k|v / out projections of the denoising UNet's "
+                         "self-attentions on the fp8 MFMA path (csrc/fp8.hip); the JSON line then says dtype bf16+fp8proj")
+    ap.add_argument("--gather", default=None, choices=["u8", "f32"],
+                    help="N > 1: what the per-wave all-gather moves -- u8 (default): the frames converted to the uint8 video bytes on "
+                         "the device (hallo_frames_to_uint8 = hallo/utils/util.py:308-312, 12.6 MB per rank at 512x512x16f); f32: "
+                         "the fp32 frames (50 MB per rank)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="CONTROL-FLOW TEST ONLY (tests/test_multigpu_cpu.py): gloo on CPU, the clip is a stub, the JSON line is "
                          "marked as not a measurement; exercises rank layout, fences, the frame all-gather and the rank-0-only legs")
@@ -348,14 +355,20 @@ def main():
     if not dry:
         from hallo_amd import lib
         lib.load()
+        from hallo_amd import ops as _ops
         if args.gemm_variant is not None:
-            from hallo_amd import ops as _ops
             _ops.set_option("gemm_variant", args.gemm_variant)
         from hallo_amd.synthetic import build_pipeline, clip_inputs
         pipe, audioproj = build_pipeline(dev, dtype)
+        if args.fp8_proj:
+            pipe.denoising_unet.set_fp8_projections(True)
     from hallo_amd.animate.clip_parallel import gather_wave
+    gather_u8 = world > 1 and (args.gather or ("f32" if dry else "u8")) == "u8"
     # rank 0 receives the whole wave (one clip per rank) and copies ALL of it to the host
-    host = torch.empty((world if rank == 0 else 1, Fr, 3, S * S), dtype=torch.float32)
+    if gather_u8:
+        host = torch.empty((world if rank == 0 else 1, Fr, S * S, 3), dtype=torch.uint8)
+    else:
+        host = torch.empty((world if rank == 0 else 1, Fr, 3, S * S), dtype=torch.float32)
     if not dry:
         host = host.pin_memory()
 
@@ -377,10 +390,14 @@ def main():
             lat = lat[0].permute(1, 2, 3, 0).reshape(Fr * h * h, 4).contiguous()
             frames, _, _ = pipe.decode_latents_device(lat, Fr, h, h)
         if world > 1 and exchange:
-            g = gather_wave(frames)                            # RCCL all-gather of decoded frames, clip order = rank
+            if gather_u8:      # the video bytes, converted on the device: 4x fewer bytes over xGMI and PCIe
+                send = (frames.clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 1).contiguous() if dry else _ops.frames_to_uint8(frames)
+            else:
+                send = frames
+            g = gather_wave(send)                              # RCCL all-gather of decoded frames, clip order = rank
             if rank == 0:
                 host.copy_(g, non_blocking=True)
-        else:
+        elif not gather_u8:
             host[0].copy_(frames, non_blocking=True)
         return frames
 
@@ -409,11 +426,12 @@ def main():
         "metric": "generated frames/sec at 512x512, 16-frame window, 25 DDIM steps",
         "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic (random-init weights of the reference architecture, synthetic clip inputs)",
+        "dtype": args.dtype + ("+fp8proj" if args.fp8_proj else ""), "data": "synthetic (random-init weights of the reference architecture, synthetic clip inputs)",
         "config": {"workload": f"BASELINE.json configs[{2 if args.guidance > 1.0 else 1}] per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
                                f"steps, guidance {args.guidance} ({'CFG, B=2' if args.guidance > 1 else 'no CFG, B=1'}), "
                                "ReferenceNet + VAE encode/decode + D2H inside the timed region",
-                   "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (" + RCCL all-gather of frames" if world > 1 else "")},
+                   "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (
+                       f" + RCCL all-gather of the decoded frames ({'uint8 video bytes' if gather_u8 else 'fp32'})" if world > 1 else "")},
     }
 
     if dry:

@@ -47,6 +47,17 @@ class GemmDesc(C.Structure):
     ]
 
 
+class GemmFp8Desc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
+        ("a_scale", C.c_void_p), ("w_scale", C.c_void_p), ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_int64),
+        ("alpha", C.c_float), ("lead_cols", C.c_int), ("lead_alpha", C.c_float), ("dtype", C.c_int),
+    ]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p),
@@ -92,6 +103,9 @@ SYMBOLS = {
     "hallo_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "hallo_get_option": (C.c_int, [C.c_char_p]),
     "hallo_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "hallo_gemm_fp8": (C.c_int, [C.POINTER(GemmFp8Desc), C.c_void_p]),
+    "hallo_quant_rows_fp8": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_float, C.c_int, C.c_void_p]),
     "hallo_conv3x3_nhwc": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "hallo_attention": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
     "hallo_temporal_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

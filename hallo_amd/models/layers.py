@@ -233,12 +233,31 @@ class Attention(nn.Module):
     def fold_norm(self, norm):
         """Constants for qkv_ln(): LN's affine folded into the fused q|k|v weight (built once per norm, see prepare)."""
         self._ln_eps = norm.eps
+        self._ln_norm = norm
         self._ln_w, self._ln_g, self._ln_b = ops.fold_layernorm(norm.weight, norm.bias, self.w_qkv, self.b_qkv)
+
+    # -- fp8 (e4m3) projections: BASELINE.json configs[4] ------------------------------------------------------------
+    fp8 = False
+
+    def set_fp8(self, enabled):
+        """Quantise [to_q; to_k; to_v] and to_out.0 per output channel (once) and route qkv_ln() / out() through
+        hallo_quant_rows_fp8 + hallo_gemm_fp8.  Needs prepared weights on the GPU; cross-attentions keep their bf16 path."""
+        if enabled and not self.is_cross and not hasattr(self, "_w8"):
+            self._w8, self._w8s = ops.quant_rows_fp8(self.w_qkv)
+            self._o8, self._o8s = ops.quant_rows_fp8(self.to_out[0].weight)
+        self.fp8 = bool(enabled) and not self.is_cross
 
     def qkv_ln(self, x, bias2=None, bias2_rows_per_group=0):
         """x [N, L, C] UN-normalised -> fused [N, L, 3*inner] of LN(x) (+ bias2: PE @ W^T rows), q pre-scaled."""
         N, L, Cd = x.shape
         x2 = x.view(N * L, Cd)
+        if self.fp8 and bias2 is None:
+            # LayerNorm + row quantisation in one pass over x, then the fp8 GEMM; the q columns carry the softmax scale
+            xq, sa = ops.quant_rows_fp8(x2, self._ln_norm.weight, self._ln_norm.bias, self._ln_eps)
+            y = ops.gemm_fp8(xq, sa, self._w8, self._w8s, x.dtype, self.b_qkv, lead_cols=self.inner,
+                             lead_alpha=ops.q_scale(self.dim_head)).view(N, L, 3 * self.inner)
+            i = self.inner
+            return y, y[:, :, :i], y[:, :, i:2 * i], y[:, :, 2 * i:]
         y = ops.gemm(x2, self._ln_w, self._ln_b, lead_cols=self.inner, lead_alpha=ops.q_scale(self.dim_head),
                      ln_colsum=self._ln_g, ln_eps=self._ln_eps,
                      ln_stats=ops.ln_stats(x2, 3 * self.inner, self._ln_eps, bias2_rows_per_group=bias2_rows_per_group if bias2 is not None else 0,
@@ -251,6 +270,9 @@ class Attention(nn.Module):
         """to_out.0 (+ residual) on a [N, L, inner]."""
         N, L, _ = a.shape
         r = residual.view(N * L, -1) if residual is not None else None
+        if self.fp8 and not epi:
+            aq, sa = ops.quant_rows_fp8(a.view(N * L, self.inner))
+            return ops.gemm_fp8(aq, sa, self._o8, self._o8s, a.dtype, self.to_out[0].bias, residual=r).view(N, L, -1)
         y = self.to_out[0].run(a.view(N * L, self.inner), residual=r, **epi)
         return y.view(N, L, -1)
 

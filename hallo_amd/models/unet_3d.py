@@ -40,7 +40,14 @@ class UNet3DConditionOutput:
 
 
 class HalloHipAttnProcessor:
-    """Name tag of the native attention path (the diffusers AttnProcessor protocol's slot)."""
+    """Name tag of the native attention path (the diffusers AttnProcessor protocol's slot).  Installing it -- or a
+    hallo_amd.attn_processor.HalloAttnProcessor, the callable form of the same kernels for the reference's torch modules --
+    is accepted; any other processor would be a PyTorch fallback and is refused."""
+
+
+def _is_native_processor(p):
+    from ..attn_processor import HalloAttnProcessor
+    return p is HalloHipAttnProcessor or p is HalloAttnProcessor or isinstance(p, (HalloHipAttnProcessor, HalloAttnProcessor))
 
 
 class _Config(dict):
@@ -151,15 +158,29 @@ class UNet3DConditionModel(HalloModule):
         return out
 
     def set_attn_processor(self, processor):
-        ok = processor is HalloHipAttnProcessor or isinstance(processor, HalloHipAttnProcessor)
+        ok = _is_native_processor(processor)
         if isinstance(processor, dict):
             if len(processor) != len(self.attn_processors):
                 raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} does "
                                  f"not match the number of attention layers: {len(self.attn_processors)}.")
-            ok = all(p is HalloHipAttnProcessor or isinstance(p, HalloHipAttnProcessor) for p in processor.values())
+            ok = all(_is_native_processor(p) for p in processor.values())
         if not ok:
             raise ValueError("hallo_amd runs attention in hand-written gfx950 kernels only; there is no PyTorch / "
                              "xformers processor fallback on this path")
+
+    def set_fp8_projections(self, enabled=True):
+        """BASELINE.json configs[4]: run the q|k|v and output projections of every self-attention of this UNet (spatial
+        transformer attn1, audio transformer attn1, motion-module attention outputs) on the fp8 MFMA path (csrc/fp8.hip):
+        activations quantised per row on the fly, weights per output channel once.  Cross-attentions (4 face / 32 audio
+        tokens: folded constants, no per-step projection of the context) are unaffected."""
+        self.prepare()
+        n = 0
+        for m in self.modules():
+            if isinstance(m, Attention) and not m.is_cross:
+                m.set_fp8(enabled)
+                n += 1
+        self.fp8_projections = bool(enabled)
+        return n
 
     def set_attention_slice(self, slice_size):
         """unet_3d.py:395-464: attention slicing trades speed for memory; the flash-style kernels never

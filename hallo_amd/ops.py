@@ -417,6 +417,39 @@ def row_stats(x2d, eps=1e-5):
     return st
 
 
+def quant_rows_fp8(x2d, gamma=None, beta=None, eps=1e-5):
+    """x2d [rows, C] (fp16 / bf16, any row stride) -> (q uint8 [rows, C] of e4m3 bytes, scale fp32 [rows]); with gamma / beta
+    the rows go through LayerNorm first (hallo_quant_rows_fp8)."""
+    _chk_dev(x2d)
+    assert x2d.dim() == 2 and x2d.stride(1) == 1
+    rows, Cd = x2d.shape
+    q = torch.empty((rows, Cd), device=x2d.device, dtype=torch.uint8)
+    sc = torch.empty((rows,), device=x2d.device, dtype=torch.float32)
+    _l.check(_l.load().hallo_quant_rows_fp8(_p(x2d), x2d.stride(0), _p(q), _p(sc), rows, Cd, _p(gamma), _p(beta), float(eps),
+                                            dtype_code(x2d.dtype), _stream()), "hallo_quant_rows_fp8")
+    return q, sc
+
+
+def gemm_fp8(aq, a_scale, wq, w_scale, out_dtype, bias=None, *, residual=None, alpha=1.0, lead_cols=0, lead_alpha=1.0, out=None):
+    """out[M, N] = alpha * lead * (a_scale[m] w_scale[n] (aq . wq^T) + bias) + residual on the fp8 MFMA (hallo_gemm_fp8)."""
+    _chk_dev(aq, wq)
+    M, K = aq.shape
+    N = wq.shape[0]
+    assert aq.dtype == torch.uint8 and wq.dtype == torch.uint8 and wq.shape[1] == K and aq.stride(1) == 1 and wq.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), device=aq.device, dtype=out_dtype)
+    d = _l.GemmFp8Desc()
+    d.A, d.B, d.C = aq.data_ptr(), wq.data_ptr(), out.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = aq.stride(0), wq.stride(0), out.stride(0)
+    d.a_scale, d.w_scale = a_scale.data_ptr(), w_scale.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.residual, d.ldr = (residual.data_ptr(), residual.stride(0)) if residual is not None else (None, 0)
+    d.alpha, d.lead_cols, d.lead_alpha, d.dtype = float(alpha), int(lead_cols), float(lead_alpha), dtype_code(out.dtype)
+    _l.check(_l.load().hallo_gemm_fp8(C.byref(d), _stream()), "hallo_gemm_fp8")
+    return out
+
+
 def ln_stats(x2d, n_out, eps=1e-5, *, geglu=False, bias2_rows_per_group=0, lead_cols=0):
     """`ln_stats` argument for a LayerNorm-fused gemm(x2d, w[n_out(, x2), K], ...): None when the library's row-stationary
     kernel will take the problem and derive mean / rstd from the A rows it keeps in registers (hallo_gemm_fuses_row_stats),

@@ -249,6 +249,36 @@ int hallo_row_stats(const void* x, float* stats, int64_t rows, int C, float eps,
 int hallo_gemm_fuses_row_stats(int M, int N, int K, int geglu, int bias2_rows_per_group, int lead_cols);
 
 /* ------------------------------------------------------------------------------------------
+ * ABI v4: fp8 (OCP e4m3) projections -- BASELINE.json configs[4] "fp8 MFMA QKV/out projections with bf16 accumulate":
+ * the diffusers Attention.to_q / to_k / to_v / to_out Linears (hallo/models/mutual_self_attention.py:253-303,
+ * hallo/models/attention.py:828-884, hallo/models/motion_module.py:553-609) with both operands quantised.
+ *
+ * hallo_quant_rows_fp8: x [rows, C] (row stride ldx, dtype) -> q [rows, C] e4m3 bytes (contiguous) and scale[rows] fp32 with
+ *   x[r, c] ~= scale[r] * decode(q[r, c]),  scale[r] = max_c |x[r, c]| / 448 (1 for an all-zero row).
+ *   gamma / beta non-NULL: y = LayerNorm(x; gamma, beta, eps) rounded to dtype is quantised instead (the norm in front of
+ *   to_q|k|v), x is read once.  C % 8 == 0, C <= 1536.  Weights are quantised once with the same call (one scale per row of
+ *   W = per output channel).
+ * hallo_gemm_fp8: C[m, n] = alpha * lead(n) * (a_scale[m] * w_scale[n] * sum_k decode(A[m,k]) decode(B[n,k]) + bias[n]) +
+ *   residual[m, n], fp32 accumulation on v_mfma_f32_32x32x16_fp8_fp8, output in `dtype` (fp16 / bf16);
+ *   lead(n) = lead_alpha for n < lead_cols else 1 (the q columns of a fused q|k|v projection carry the softmax scale).
+ *   K % 16 == 0, N % 8 == 0, lda / ldb multiples of 16 bytes, A / B / C 16-byte aligned. */
+int hallo_quant_rows_fp8(const void* x, int64_t ldx, void* q, float* scale, int64_t rows, int C, const void* gamma,
+                         const void* beta, float eps, int dtype, void* stream);
+typedef struct {
+  const void* A; const void* B; void* C;     /* A [M, K] e4m3, B [N, K] e4m3, C [M, N] dtype */
+  int M, N, K;
+  int64_t lda, ldb, ldc;                     /* lda / ldb in bytes (= elements), ldc in elements */
+  const float* a_scale;                      /* [M] */
+  const float* w_scale;                      /* [N] */
+  const void* bias;                          /* [N] dtype or NULL */
+  const void* residual; int64_t ldr;         /* [M, N] dtype or NULL */
+  float alpha;
+  int lead_cols; float lead_alpha;
+  int dtype;
+} hallo_gemm_fp8_desc;
+int hallo_gemm_fp8(const hallo_gemm_fp8_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * hallo_face_xattn: y = x + to_out(SDPA(to_q(LayerNorm(x)), K_face, V_face)) for a cross-attention over H*T = 32
  * (head, token) pairs -- norm2 + attn2 + residual of the spatial transformer block
  * (hallo/models/mutual_self_attention.py:286-303; 4 face tokens x 8 heads) in ONE pass over x.

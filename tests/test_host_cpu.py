@@ -44,6 +44,9 @@ def test_plugin_surface():
     # 16 spatial blocks x (attn1, attn2) + 16 audio blocks x (attn1 + 3 cross) ; temporal transformers excluded
     assert len(procs) == 16 * 2 + 16 * 4 and all("temporal_transformer" not in k for k in procs)
     m.set_attn_processor(HalloHipAttnProcessor())
+    from hallo_amd.attn_processor import HalloAttnProcessor          # the callable form of the same kernels
+    m.set_attn_processor(HalloAttnProcessor())
+    m.set_attn_processor({k: HalloAttnProcessor() for k in procs})
     m.set_attention_slice("auto")
     with pytest.raises(ValueError):
         m.set_attn_processor(object())            # no PyTorch / xformers fallback on this path

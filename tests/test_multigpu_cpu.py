@@ -85,3 +85,15 @@ def test_bench_control_flow_world1():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["dry_run_wave"] == [2.0]
+
+
+def test_two_rank_clip_wave_matches_single_rank(tmp_path):
+    """The worker of tests/test_multigpu_gpu.py (two ranks, one clip each through FaceAnimatePipeline, frame exchange, rank 0
+    re-runs both clips alone and asserts byte identity) on CPU: gloo + the operator emulation.  Checks the plumbing of the
+    GPU test, which itself needs two devices."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_multigpu_gpu as G
+    port = 29800 + (os.getpid() % 2000)
+    mp.spawn(G.clip_worker, args=(2, port, "gloo", str(tmp_path)), nprocs=2, join=True)
+    wave = torch.load(tmp_path / "wave.pt")
+    assert wave.shape == (2, 2, 64 * 64, 3) and wave.dtype == torch.uint8 and not torch.equal(wave[0], wave[1])

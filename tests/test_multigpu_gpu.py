@@ -1,0 +1,75 @@
+"""Clip-parallel inference on real devices (SURVEY 8e, section 7 "N-GPU == 1-GPU bit-identical per clip"): two ranks, one clip
+each on its own GPU through FaceAnimatePipeline + the frame exchange (gather_wave: RCCL all-gather of the uint8 frames),
+then rank 0 re-runs both clips alone on its device and asserts BYTE identity with what the gather delivered.
+
+Needs >= 2 visible GPUs: skipped on the 1-GPU boxes this repository is developed on (no scaling curve exists yet -- DESIGN
+section 8).  The same worker runs on the CPU (gloo, operator emulation) in tests/test_multigpu_cpu.py so that its plumbing --
+process group, device placement, gather order, comparison -- is exercised without GPUs."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def clip_worker(rank, world, port, backend, out_dir):
+    """One rank of the 2-clip wave.  backend "nccl": cuda:<rank>, the real library; "gloo": CPU + tests/emu_ops.py."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    mp_ctx = None
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import emu_ops
+        mp_ctx = pytest.MonkeyPatch()
+        emu_ops.install(mp_ctx)
+        torch.set_num_threads(2)
+    from oracle import harness as Hn
+    from hallo_amd.animate import clip_parallel as cp
+    from hallo_amd.animate import video as V
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.synthetic import make_scheduler
+    dtype = torch.float16 if backend == "nccl" else torch.float32
+    o = Hn.oracle_nets(dtype=dtype if backend == "nccl" else torch.float32)
+    S, Fr, steps = 64, 2, 2
+
+    def run_clip(idx, device):
+        n = Hn.native_nets(o, dtype=dtype, device=str(device))
+        pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+                                   face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=make_scheduler())
+        d = Hn.clip_inputs(S, Fr, seed=1234 + idx)
+        vid = pipe(d["ref_image"], d["face_emb"], d["audio"], d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr, steps, 3.5,
+                   motion_scale=d["motion_scale"], latents=d["latents"]).videos            # (1, 3, F, S, S) fp32 CPU
+        frames = vid[0].permute(1, 0, 2, 3).reshape(Fr, 3, S * S).contiguous().to(device)
+        return V.frames_to_uint8(frames) if backend == "nccl" else (frames.clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 1).contiguous()
+
+    mine = run_clip(rank, dev)                                  # clip index == rank: one wave
+    wave = cp.gather_wave(mine)                                 # [world, F, HW, 3] uint8, entry w = clip of rank w
+    assert wave.shape[0] == world and wave.dtype == torch.uint8
+    if rank == 0:
+        for idx in range(world):                                # the 1-GPU result of every clip, on rank 0's device
+            alone = run_clip(idx, dev)
+            assert torch.equal(wave[idx].cpu(), alone.cpu()), f"clip {idx}: N-GPU result differs from the 1-GPU result"
+        torch.save(wave.cpu(), os.path.join(out_dir, "wave.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+    if mp_ctx is not None:
+        mp_ctx.undo()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (the development boxes have one)")
+def test_two_gpus_byte_identical_to_one(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29700 + (os.getpid() % 2000)
+    mp.spawn(clip_worker, args=(2, port, "nccl", str(tmp_path)), nprocs=2, join=True)
+    wave = torch.load(tmp_path / "wave.pt")
+    assert wave.shape == (2, 2, 64 * 64, 3) and not torch.equal(wave[0], wave[1])     # two different clips came back

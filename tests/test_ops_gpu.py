@@ -667,3 +667,38 @@ def test_operators_are_bit_reproducible():
             ref = fn().clone()
             for _ in range(4):
                 assert torch.equal(fn(), ref), (name, dtype)
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd,Lq,ctx_len", [(40, 1024, None), (80, 256, 77), (160, 64, None)])
+def test_attn_processor_plugin_seam(dtype, hd, Lq, ctx_len, report):
+    """INTEGRATION.md section B executed: the diffusers `Attention` module of the reference's stack (the stand-in of diffusers
+    0.27.2 that the oracle runs on) with hallo_amd.attn_processor.HalloAttnProcessor installed through `set_processor` --
+    the reference's plugin hook (hallo/models/unet_3d.py:471-508) -- against the same module with its default
+    AttnProcessor2_0 (F.scaled_dot_product_attention) in fp32: self-attention and cross-attention, residual connection."""
+    from oracle import harness  # noqa: F401  (puts the diffusers stand-in on the path)
+    from diffusers.models.attention_processor import Attention, AttnProcessor2_0
+    from hallo_amd.attn_processor import HalloAttnProcessor
+    g = torch.Generator().manual_seed(hd + Lq)
+    H, B = 8, 2
+    Cd = H * hd
+    cross = 768 if ctx_len else None
+    ref_mod = Attention(query_dim=Cd, cross_attention_dim=cross, heads=H, dim_head=hd, bias=False, residual_connection=ctx_len is None)
+    with torch.no_grad():
+        for p in ref_mod.parameters():
+            p.copy_(((torch.rand(p.shape, generator=g) * 2 - 1) * (p.shape[-1] ** -0.5)).to(dtype).float())
+    x = _rand((B, Lq, Cd), dtype, g)
+    ctx = _rand((B, ctx_len, cross), dtype, g) if ctx_len else None
+    ref_mod = ref_mod.to(_dev())
+    assert isinstance(ref_mod.processor, AttnProcessor2_0)
+    with torch.no_grad():
+        ref = ref_mod(x.float(), encoder_hidden_states=ctx.float() if ctx is not None else None)
+        mod = Attention(query_dim=Cd, cross_attention_dim=cross, heads=H, dim_head=hd, bias=False, residual_connection=ctx_len is None)
+        mod.load_state_dict(ref_mod.state_dict())
+        mod = mod.to(device=_dev(), dtype=dtype)
+        mod.set_processor(HalloAttnProcessor())
+        out = mod(x, encoder_hidden_states=ctx)
+    _check(f"attn_processor_seam[{hd},{Lq},{ctx_len}]", out, ref, dtype, report, scale=2.0)     # + the torch projections' rounding
+    with pytest.raises(NotImplementedError):
+        mod(x, encoder_hidden_states=ctx, attention_mask=torch.zeros((B, 1, Lq), device=_dev()))
