@@ -269,9 +269,14 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(s_cur[t][r], s_cur[t][r + 1]), mx);
-    {   // the partner lane (lane ^ 32) holds the other half of the row: one VALU half-swap instead of an LDS round trip
-      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
-      mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    {   // the partner lane (lane ^ 32) holds the other half of the row: one VALU half-swap instead of an LDS round trip.
+        // Written as inline asm: through __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2) folds fmaxf(sw[0], sw[1]) to
+        // sw[0] (ISA: v_permlane32_swap v32, v33 ; v_max_f32 v32, v32, v32 -- with identical or distinct operands), so the
+        // maximum covered the hi = 0 half of the keys only.  That is still a valid softmax reference value (results were
+        // right), but P was then unbounded: fp16 rows whose other half was > 2^10 larger overflowed to inf / NaN (found by
+        // the run-to-run identity test, whose q is unscaled).  s_nop 1: VALU write -> permlane read wait states.
+      float mx_hi = mx;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(mx), "+v"(mx_hi));
     }
     // s_cur holds s - m_run (m_run = 0 before the first tile, which always takes this branch); deferred rescale
     if (__builtin_expect(it == 0 || !__all(mx <= RESCALE_THR), 0)) {
@@ -373,8 +378,10 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
       if (live) *reinterpret_cast<uint4*>(orow + 8 * g + 8 * hi) = make_uint4(x[0], y[0], x[1], y[1]);
     }
     {                                    // d 32 .. 39: lanes hi = 0 collect the partner's half and store alone
-      const auto x = __builtin_amdgcn_permlane32_swap(pk[4][0], pk[4][0], false, false);
-      const auto y = __builtin_amdgcn_permlane32_swap(pk[4][1], pk[4][1], false, false);
+      unsigned c0 = pk[4][0], c1 = pk[4][1];           // opaque copies: see the note at the row-maximum exchange
+      asm volatile("" : "+v"(c0), "+v"(c1));
+      const auto x = __builtin_amdgcn_permlane32_swap(pk[4][0], c0, false, false);
+      const auto y = __builtin_amdgcn_permlane32_swap(pk[4][1], c1, false, false);
       if (live && !hi) *reinterpret_cast<uint4*>(orow + 32) = make_uint4(x[0], y[0], x[1], y[1]);
     }
   }

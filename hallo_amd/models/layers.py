@@ -233,7 +233,7 @@ class Attention(nn.Module):
     def fold_norm(self, norm):
         """Constants for qkv_ln(): LN's affine folded into the fused q|k|v weight (built once per norm, see prepare)."""
         self._ln_eps = norm.eps
-        self._ln_norm = norm
+        self.__dict__["_ln_norm"] = norm     # plain attribute: registering it as a submodule would add state-dict keys
         self._ln_w, self._ln_g, self._ln_b = ops.fold_layernorm(norm.weight, norm.bias, self.w_qkv, self.b_qkv)
 
     # -- fp8 (e4m3) projections: BASELINE.json configs[4] ------------------------------------------------------------
