@@ -312,7 +312,7 @@ static int cmd_attn_nan(int argc, char** argv) {
 // ---------------------------------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------------------------------
-struct GemmOpts { int M, N, K; bool geglu = false, ln = false, res = false; int rs = -1, variant = -1; int dt = DT_BF16; bool check = true; };
+struct GemmOpts { int M, N, K; bool geglu = false, ln = false, res = false; int rs = -1, variant = -1, rsdbg = 0; int dt = DT_BF16; bool check = true; };
 
 static void run_gemm_case(const GemmOpts& g, Timer& tm) {
   const int wrows = g.geglu ? 2 * g.N : g.N, dt = g.dt;
@@ -327,6 +327,7 @@ static void run_gemm_case(const GemmOpts& g, Timer& tm) {
   if (g.ln) hipLaunchKernelGGL(fold_ln, dim3((wrows + 63) / 64), dim3(64), 0, 0, W, bias, gamma, beta, Wf, bf, cs, wrows, g.K, dt);
   if (g.rs >= 0) HK(hallo_set_option("gemm_rs", g.rs));
   if (g.variant >= 0) HK(hallo_set_option("gemm_variant", g.variant));
+  HK(hallo_set_option("gemm_rs_dbg", g.rsdbg));
   hallo_gemm_desc d; memset(&d, 0, sizeof d);
   d.A = A; d.B = g.ln ? Wf : W; d.C = Cc; d.M = g.M; d.N = g.N; d.K = g.K; d.lda = g.K; d.ldb = g.K; d.ldc = g.N; d.batch = 1;
   d.bias = g.ln ? bf : bias; d.residual = R; d.ldr = g.N; d.alpha = 1.0f; d.geglu = g.geglu; d.dtype = dt; d.lead_alpha = 1.0f;
@@ -359,14 +360,15 @@ static void run_gemm_case(const GemmOpts& g, Timer& tm) {
   std::vector<float> t; for (int r = 0; r < 5; ++r) t.push_back(tm.run(launch, 10));
   const float us = median(t);
   const double flop = 2.0 * g.M * (double)wrows * g.K, bytes = 2.0 * ((double)g.M * g.K + (double)wrows * g.K + (double)g.M * g.N * (g.res ? 2 : 1));
-  printf("gemm M=%d N=%d K=%d%s%s%s dt=%s rs=%d variant=%d kernel=%d fused_stats=%d: %.1f us  %.1f TFLOP/s  %.0f GB/s  rel_l2(first rows)=%.2e nan=%ld nondet=%d\n",
-         g.M, g.N, g.K, g.geglu ? " geglu" : "", g.ln ? " ln" : "", g.res ? " res" : "", dt ? "bf16" : "f16", g.rs, g.variant, kern, (int)fused_stats,
+  printf("gemm M=%d N=%d K=%d%s%s%s dt=%s rs=%d variant=%d rsdbg=%d kernel=%d fused_stats=%d: %.1f us  %.1f TFLOP/s  %.0f GB/s  rel_l2(first rows)=%.2e nan=%ld nondet=%d\n",
+         g.M, g.N, g.K, g.geglu ? " geglu" : "", g.ln ? " ln" : "", g.res ? " res" : "", dt ? "bf16" : "f16", g.rs, g.variant, g.rsdbg, kern, (int)fused_stats,
          us, flop / us / 1e6, bytes / us / 1e3, rel, nan, nondet);
   fflush(stdout);
   CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(Wf)); CK(hipFree(bias)); CK(hipFree(bf)); CK(hipFree(gamma)); CK(hipFree(beta)); CK(hipFree(cs));
   CK(hipFree(Cc)); if (R) CK(hipFree(R)); CK(hipFree(stats));
   if (g.rs >= 0) HK(hallo_set_option("gemm_rs", 1));
   if (g.variant >= 0) HK(hallo_set_option("gemm_variant", 6));
+  HK(hallo_set_option("gemm_rs_dbg", 0));
 }
 
 static GemmOpts parse_gemm(int argc, char** argv) {
@@ -375,6 +377,7 @@ static GemmOpts parse_gemm(int argc, char** argv) {
     std::string a = argv[i];
     if (a == "geglu") g.geglu = true; else if (a == "ln") g.ln = true; else if (a == "res") g.res = true; else if (a == "nocheck") g.check = false;
     else if (a == "f16") g.dt = DT_F16; else if (a.rfind("rs=", 0) == 0) g.rs = atoi(a.c_str() + 3); else if (a.rfind("variant=", 0) == 0) g.variant = atoi(a.c_str() + 8);
+    else if (a.rfind("rsdbg=", 0) == 0) { g.rsdbg = atoi(a.c_str() + 6); if (g.rsdbg) g.check = false; }
   }
   return g;
 }
