@@ -86,6 +86,24 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + __builtin_copysignf(erf_abs, x));
 }
 
+// The same erf (A&S 7.1.26) arranged for a VALU-bound epilogue.  With u = x * sqrt(log2(e) / 2):
+//   gelu(x) = relu(x) - |x| * Phi(-|x|),  Phi(-|x|) = 0.5 * t * poly(t) * 2^(-u^2),  t = 1 / (1 + p' |u|),  p' = p * sqrt(2 / log2 e) / sqrt 2
+// so the sign handling (copysign, 1 + erf) disappears and the 0.5 lives in the coefficients.  gelu_u(u) returns
+// gelu(x) / GELU_U_INV with GELU_U_INV = sqrt(2 / log2 e): the caller scales the argument by GELU_U_SCALE and the product by
+// GELU_U_INV inside multiplications it performs anyway (LayerNorm affine of gate and value).  12 VALU ops.
+constexpr float GELU_U_SCALE = 0.84932180028801904272f;    // sqrt(log2(e) / 2)
+constexpr float GELU_U_INV = 1.17741002251547469101f;      // 1 / GELU_U_SCALE
+__device__ __forceinline__ float gelu_u(float u) {
+  const float au = fabsf(u);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.83255461115769775635f, au, 1.0f));   // p * z, z = |x| / sqrt 2 = |u| / sqrt(log2 e)
+  float q = __builtin_fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  q = __builtin_fmaf(q, t, 0.5f * 1.421413741f);
+  q = __builtin_fmaf(q, t, 0.5f * -0.284496736f);
+  q = __builtin_fmaf(q, t, 0.5f * 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-(u * u));
+  return __builtin_fmaf(-au, (q * t) * e, fmaxf(u, 0.0f));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -782,7 +782,7 @@ static int g_v3_min_tiles = 192; // auto: smallest grid (workgroups, 1 per CU) w
 // 1000 * LNF (gemm2: 0 none, 1 in-loop LayerNorm statistics, 2 external) + 100 * kernel (1 gemm_kernel, 2 gemm2_kernel,
 // 3 gemm3_kernel) + 10 * mode (0 gemm, 1 conv, 2 geglu) + stages / TM (+ 4 for the persistent gemm3 mode)
 static int g_last_kernel = 0;
-static int g_gemm_rs = 1;        // hallo_set_option("gemm_rs", 0 | 1): row-stationary kernel (gemm_rs.hip) for eligible K = 320 / 640 shapes
+static int g_gemm_rs = 2;        // hallo_set_option("gemm_rs", 0 | 1 | 2): row-stationary kernels for eligible K = 320 / 640 shapes (1: gemm_rs.hip only, 2: gemm_rs2.hip at K = 320)
 
 
 template <typename T>
@@ -792,6 +792,11 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
   int v = a.vec_ok ? g_gemm_variant : 0;
   const bool lnf = a.ln_colsum != nullptr;      // fused LayerNorm: 128x128 LDS-DMA kernel only, no split-K
   const bool gelu = a.act >= ACT_GELU;          // GELU epilogues (wav2vec2 front-end): own instantiation of the 128x128 kernel
+  if (g_gemm_rs >= 2 && v >= 3 && a.vec_ok && gemm_rs2_eligible(a, conv, geglu, batch)) {
+    // 5xx: gemm_rs2_kernel (K = 320, pipelined epilogue): + 10 * mode (0 gemm, 2 geglu) + 1, + 1000 with LayerNorm
+    g_last_kernel = 500 + (geglu ? 20 : 0) + 1 + (lnf ? 1000 : 0);
+    return launch_gemm_rs2<T>(a, geglu, st);
+  }
   if (g_gemm_rs && v >= 3 && a.vec_ok && gemm_rs_eligible(a, conv, geglu, batch)) {
     // 4xx: gemm_rs_kernel (A rows in registers, W streamed): + 10 * mode (0 gemm, 2 geglu) + (1: K = 320, 2: K = 640), + 1000 with LayerNorm
     g_last_kernel = 400 + (geglu ? 20 : 0) + (a.K == 320 ? 1 : 2) + (lnf ? 1000 : 0);
@@ -973,6 +978,8 @@ extern "C" int hallo_gemm_fuses_row_stats(int M, int N, int K, int geglu, int bi
   a.bias2 = bias2_rows_per_group > 0 ? reinterpret_cast<const void*>(16) : nullptr;
   a.bias2_rpg = bias2_rows_per_group > 0 ? bias2_rows_per_group : 1;
   a.lead_cols = lead_cols; a.splits = 1; a.act = ACT_NONE;
+  a.A = a.C = reinterpret_cast<void*>(16);      // alignment checks of the eligibility rules: hallo_gemm requires 16-byte pointers anyway
+  if (g_gemm_rs >= 2 && gemm_rs2_eligible(a, false, geglu != 0, 1)) return 1;
   return gemm_rs_eligible(a, false, geglu != 0, 1) ? 1 : 0;
 }
 
@@ -1026,7 +1033,7 @@ extern "C" int hallo_set_option(const char* name, int value) {
   if (!strcmp(name, "v3_min_tiles")) { if (value < 1) return -22; g_v3_min_tiles = value; return 0; }
   if (!strcmp(name, "conv_fast")) { if (value < 0 || value > 1) return -22; g_conv_fast = value; return 0; }
   if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }
-  if (!strcmp(name, "gemm_rs")) { if (value < 0 || value > 1) return -22; g_gemm_rs = value; return 0; }
-  if (!strcmp(name, "gemm_rs_dbg")) { set_gemm_rs_dbg(value); return 0; }
+  if (!strcmp(name, "gemm_rs")) { if (value < 0 || value > 2) return -22; g_gemm_rs = value; return 0; }
+  if (!strcmp(name, "gemm_rs_dbg")) { set_gemm_rs_dbg(value); set_gemm_rs2_dbg(value); return 0; }
   return hallo_set_option_norm(name, value);
 }

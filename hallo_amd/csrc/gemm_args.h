@@ -47,4 +47,9 @@ bool gemm_rs_eligible(const GemmArgs& a, bool conv, bool geglu, int batch);
 template <typename T> int launch_gemm_rs(const GemmArgs& a, bool geglu, hipStream_t st);
 void set_gemm_rs_dbg(int v);
 
+// gemm_rs2.hip: the K = 320 row-stationary kernel with the epilogue of a W block pair interleaved into the next pair's MFMAs.
+bool gemm_rs2_eligible(const GemmArgs& a, bool conv, bool geglu, int batch);
+template <typename T> int launch_gemm_rs2(const GemmArgs& a, bool geglu, hipStream_t st);
+void set_gemm_rs2_dbg(int v);
+
 }  // namespace hallo

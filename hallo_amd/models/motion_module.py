@@ -68,9 +68,13 @@ class TemporalTransformerBlock(nn.Module):
             self._pe_bias[key] = rows.repeat(batch, 1).contiguous()
         return self._pe_bias[key]
 
-    def run(self, h, batch, frames):
-        """h [batch*frames, L, C]"""
+    def run(self, h, batch, frames, drop=0):
+        """h [batch*frames, L, C].  drop > 0 (batch 1 only): the caller discards the first `drop` frames of the result (the
+        motion frames put in front of the clip, unet_3d_blocks.py:696-748).  Everything behind the LAST temporal attention is
+        row-wise (to_out, the feed-forward, proj_out), so those rows are not computed at all: the frames still take part as
+        keys / values, the kept rows are bit-for-bit what the full computation gives, and [frames - drop, L, C] is returned."""
         n, L, Cd = h.shape
+        last = len(self.attention_blocks) - 1
         for i, (attn, norm) in enumerate(zip(self.attention_blocks, self.norms)):
             wf, gcs, bf = self._ln[i]
             # row r = (b*frames + f)*L + pixel -> bias2 row r / L
@@ -79,6 +83,8 @@ class TemporalTransformerBlock(nn.Module):
                            ln_stats=ops.ln_stats(h2, 3 * Cd, norm.eps, bias2_rows_per_group=L),
                            bias2=self._pe_rows(i, attn, batch, frames), bias2_rows_per_group=L).view(n, L, 3 * Cd)
             a = ops.temporal_attention(qkv, batch, frames, L, Cd, attn.heads)
+            if drop and i == last:
+                a, h = a[drop:], h[drop:]
             h = attn.out(a, residual=h)
         return self.ff.run_ln(h)
 
@@ -94,13 +100,16 @@ class TemporalTransformer3DModel(nn.Module):
             [TemporalTransformerBlock(inner, heads, head_dim, n_attn, max_len) for _ in range(num_layers)])
         self.proj_out = Linear(inner, in_channels)
 
-    def run(self, x, batch, frames):
+    def run(self, x, batch, frames, drop=0):
         n, L, Cd = x.shape
+        assert drop == 0 or batch == 1
         h = self.norm.run(x)
         h = self.proj_in.run(h.view(n * L, Cd)).view(n, L, self.inner)
-        for blk in self.transformer_blocks:
-            h = blk.run(h, batch, frames)
-        return self.proj_out.run(h.view(n * L, self.inner), residual=x.view(n * L, Cd)).view(n, L, Cd)
+        nb = len(self.transformer_blocks)
+        for i, blk in enumerate(self.transformer_blocks):
+            h = blk.run(h, batch, frames, drop if i == nb - 1 else 0)
+        k = h.shape[0]                                       # n, or n - drop
+        return self.proj_out.run(h.view(k * L, self.inner), residual=x[n - k:].view(k * L, Cd)).view(k, L, Cd)
 
 
 class VanillaTemporalModule(nn.Module):
@@ -112,5 +121,5 @@ class VanillaTemporalModule(nn.Module):
             in_channels, num_attention_heads, in_channels // num_attention_heads // temporal_attention_dim_div,
             num_transformer_block, len(attention_block_types), temporal_position_encoding_max_len, norm_num_groups)
 
-    def run(self, x, batch, frames):
-        return self.temporal_transformer.run(x, batch, frames)
+    def run(self, x, batch, frames, drop=0):
+        return self.temporal_transformer.run(x, batch, frames, drop)

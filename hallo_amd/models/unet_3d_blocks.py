@@ -86,9 +86,11 @@ def _layer(st, x, H, W, attn, audio, motion, depth):
     else:
         x = audio.run_audio(x, st.audio, masks, st.motion_scale, st.cache)
         ops.copy2d(x.view(B, F * L * Cd), cat2[:, nm * L * Cd:], B, F * L * Cd)
-    y = motion.run(cat.view(B * Ft, L, Cd), B, Ft)
     if B == 1:
-        return y[nm:]
+        # the motion frames' rows of the result would be sliced off: the module skips everything behind its last temporal
+        # attention for them (row-wise work, 2 of 18 frames)
+        return motion.run(cat.view(Ft, L, Cd), 1, Ft, drop=nm)
+    y = motion.run(cat.view(B * Ft, L, Cd), B, Ft)
     out = torch.empty((n, L, Cd), device=x.device, dtype=x.dtype)
     ops.copy2d(y.view(B, Ft * L * Cd)[:, nm * L * Cd:], out.view(B, F * L * Cd), B, F * L * Cd)
     return out

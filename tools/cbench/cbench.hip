@@ -89,10 +89,10 @@ __global__ void attn_ref(const uint16_t* q, const uint16_t* k1, const uint16_t* 
 
 // naive GEMM reference (fp32): C = A . W^T (+ bias), optional LayerNorm on A rows (fp32 statistics), optional GEGLU
 __global__ void gemm_ref(const uint16_t* A, const uint16_t* W, const uint16_t* bias, const uint16_t* gamma, const uint16_t* beta,
-                         const uint16_t* res, float* C, int M, int N, int K, int geglu, int ln, int dt, int rows) {
+                         const uint16_t* res, float* C, int M, int N, int K, int geglu, int ln, int dt, int rows, int row0) {
   long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i >= (long)rows * N) return;
-  int n = i % N; int m = i / N;
+  int n = i % N; int m = row0 + i / N;
   float mean = 0.0f, rstd = 1.0f;
   if (ln) {
     float s = 0.0f, s2 = 0.0f;
@@ -312,7 +312,7 @@ static int cmd_attn_nan(int argc, char** argv) {
 // ---------------------------------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------------------------------
-struct GemmOpts { int M, N, K; bool geglu = false, ln = false, res = false; int rs = -1, variant = -1, rsdbg = 0; int dt = DT_BF16; bool check = true; };
+struct GemmOpts { int M, N, K; bool geglu = false, ln = false, res = false; int rs = -1, variant = -1, rsdbg = 0; float ascale = 1.0f, wscale = 1.0f; int dt = DT_BF16; bool check = true; };
 
 static void run_gemm_case(const GemmOpts& g, Timer& tm) {
   const int wrows = g.geglu ? 2 * g.N : g.N, dt = g.dt;
@@ -321,7 +321,7 @@ static void run_gemm_case(const GemmOpts& g, Timer& tm) {
   uint16_t* gamma = dalloc<uint16_t>(g.K); uint16_t* beta = dalloc<uint16_t>(g.K); float* cs = dalloc<float>(wrows);
   uint16_t* Cc = dalloc<uint16_t>((long)g.M * g.N); uint16_t* R = g.res ? dalloc<uint16_t>((long)g.M * g.N) : nullptr;
   float* stats = dalloc<float>((long)g.M * 2);
-  fill(A, (long)g.M * g.K, 1, 1.0f, 0.3f, dt); fill(W, (long)wrows * g.K, 2, 1.0f / sqrtf((float)g.K), 0.0f, dt);
+  fill(A, (long)g.M * g.K, 1, g.ascale, 0.3f * g.ascale, dt); fill(W, (long)wrows * g.K, 2, g.wscale / sqrtf((float)g.K), 0.0f, dt);
   fill(bias, wrows, 3, 1.0f, 0.0f, dt); fill(gamma, g.K, 4, 0.1f, 1.0f, dt); fill(beta, g.K, 5, 0.1f, 0.0f, dt);
   if (R) fill(R, (long)g.M * g.N, 6, 1.0f, 0.0f, dt);
   if (g.ln) hipLaunchKernelGGL(fold_ln, dim3((wrows + 63) / 64), dim3(64), 0, 0, W, bias, gamma, beta, Wf, bf, cs, wrows, g.K, dt);
@@ -344,12 +344,16 @@ static void run_gemm_case(const GemmOpts& g, Timer& tm) {
   if (g.check) {
     const int rows = std::min(g.M, 512);
     float* ref = dalloc<float>((long)rows * g.N);
-    hipLaunchKernelGGL(gemm_ref, dim3(((long)rows * g.N + 255) / 256), dim3(256), 0, 0, A, W, bias, gamma, beta, R, ref, g.M, g.N, g.K,
-                       (int)g.geglu, (int)g.ln, dt, rows);
     std::vector<float> href((long)rows * g.N); std::vector<uint16_t> out((long)g.M * g.N), out2((long)g.M * g.N);
-    CK(hipMemcpy(href.data(), ref, href.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(out.data(), Cc, out.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(out.data(), Cc, out.size() * 2, hipMemcpyDeviceToHost));
     double en = 0, rn = 0;
-    for (long i = 0; i < (long)rows * g.N; ++i) { float x = host_to_f(out[i], dt); if (x != x) ++nan; double e = x - href[i]; en += e * e; rn += (double)href[i] * href[i]; }
+    for (int part = 0; part < 2; ++part) {          // the first and the last `rows` rows
+      const int row0 = part ? g.M - rows : 0;
+      hipLaunchKernelGGL(gemm_ref, dim3(((long)rows * g.N + 255) / 256), dim3(256), 0, 0, A, W, bias, gamma, beta, R, ref, g.M, g.N, g.K,
+                         (int)g.geglu, (int)g.ln, dt, rows, row0);
+      CK(hipMemcpy(href.data(), ref, href.size() * 4, hipMemcpyDeviceToHost));
+      for (long i = 0; i < (long)rows * g.N; ++i) { float x = host_to_f(out[(long)row0 * g.N + i], dt); if (x != x) ++nan; double e = x - href[i]; en += e * e; rn += (double)href[i] * href[i]; }
+    }
     // also the last 256 rows region sanity: NaN scan over everything
     for (long i = 0; i < (long)g.M * g.N; ++i) { float x = host_to_f(out[i], dt); if (x != x) ++nan; }
     rel = sqrt(en / rn);
@@ -377,6 +381,7 @@ static GemmOpts parse_gemm(int argc, char** argv) {
     std::string a = argv[i];
     if (a == "geglu") g.geglu = true; else if (a == "ln") g.ln = true; else if (a == "res") g.res = true; else if (a == "nocheck") g.check = false;
     else if (a == "f16") g.dt = DT_F16; else if (a.rfind("rs=", 0) == 0) g.rs = atoi(a.c_str() + 3); else if (a.rfind("variant=", 0) == 0) g.variant = atoi(a.c_str() + 8);
+    else if (a == "zeroA") { g.ascale = 0.0f; g.check = false; } else if (a == "zeroW") { g.wscale = 0.0f; g.check = false; }
     else if (a.rfind("rsdbg=", 0) == 0) { g.rsdbg = atoi(a.c_str() + 6); if (g.rsdbg) g.check = false; }
   }
   return g;
