@@ -72,6 +72,8 @@ class OpProfiler:
             if kern == 4:      # row-stationary kernel (csrc/gemm_rs.hip): <T, K/16, W blocks per chunk, geglu, layernorm>
                 return "gemm_rs_kernel<%s,%d,%d,%s,%s>" % (dt, 20 if sub == 1 else 40, 4 if sub == 1 else 2,
                                                            "true" if mode == 2 else "false", "true" if lnf else "false")
+            if kern == 5:      # csrc/gemm_rs2.hip (K = 320, epilogue sliced between the MFMAs): <T, geglu, layernorm, ablation>
+                return "gemm_rs2_kernel<%s,%s,%s,0>" % (dt, "true" if mode == 2 else "false", "true" if lnf else "false")
             return "gemm3_kernel<%s,%d,%d,%s>" % (dt, mode, sub & 3, "true" if sub & 4 else "false")
         if name == "attention":
             hd = a[0].shape[-1] // a[3]

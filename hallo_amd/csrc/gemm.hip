@@ -806,13 +806,16 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     if (conv || geglu || lnf) return -22;
     if (v >= 4) v = 3;
   }
+  // LayerNorm-fused problems run on the 128x128 kernel -- or on the big tile (whose epilogue applies rstd * (acc - mean * G[n]))
+  // when the caller supplies the row statistics and the column sums are 16-byte aligned; split-K is off for them
+  const bool lnf3 = lnf && a.ln_stats != nullptr && !(reinterpret_cast<uintptr_t>(a.ln_colsum) & 15) && !(a.N & 3) && !conv;
   if (lnf) {
     if (!a.vec_ok || conv) return -22;
-    v = (v == 1 || v == 2) ? v : 3;
+    if (!(lnf3 && v >= 4)) v = (v == 1 || v == 2) ? v : 3;
   }
 
   // ---- big-tile kernel (gemm3.hip): 256x320 or 128x320 output tiles, one workgroup per CU ----
-  if (v >= 4 && !lnf) {
+  if (v >= 4 && (!lnf || lnf3)) {
     const bool ok3 = (a.K % 64 == 0) && (!conv || a.conv_fast) && a.N >= 160;
     const int tn3 = geglu ? (a.N + 159) / 160 : (a.N + 319) / 320;
     const float n_eff = (float)a.N / (float)(tn3 * (geglu ? 160 : 320));
@@ -821,7 +824,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     bool persist = false;
     // Split-K factor that brings a grid of `tiles` workgroups to ~one per CU (long K only; fp32 slabs + reduce pass).
     auto split_for = [&](int tiles) {
-      if (tiles >= g_v3_min_tiles || geglu || batch != 1 || !g_split_k || !ws || nk < 16) return 1;
+      if (tiles >= g_v3_min_tiles || geglu || lnf || batch != 1 || !g_split_k || !ws || nk < 16) return 1;
       int f = (256 + tiles - 1) / tiles;
       if (f > nk / 8) f = nk / 8;
       if (f > 8) f = 8;
@@ -840,11 +843,16 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
         //   workgroup, else 128-row tiles;  GEMM / GEGLU: K >= 1280 and a grid that fills the chip.
         // One workgroup per CU: a grid of g workgroups runs in ceil(g / 256) rounds, so e.g. 288 tiles cost two full
         // rounds (56 % efficiency).  Require >= 85 % of the last round to be filled.
-        auto fills = [&](int g) { const int rounds = (g + 255) / 256; return g >= g_v3_min_tiles && g * 100 >= rounds * 256 * 85; };
+        auto fills = [&](int g) { const int rounds = (g + 255) / 256; return g >= g_v3_min_tiles && g * 100 >= rounds * 256 * 84; };
         const int sp256 = split_for(t256), sp128 = split_for(t128);
         if (conv && a.stride == 1) {
           if (fills(t256 * sp256) && (sp256 == 1 || nk / sp256 >= 40)) { tm = 2; sp = sp256; }
           else if (t128 <= 64 && fills(t128 * sp128)) { tm = 1; sp = sp128; }     // 8x8 feature maps: 128-row tiles, deep split
+        } else if (!conv && geglu) {
+          // GEGLU (r2 A/B with the LayerNorm epilogue, tools/cbench/g3.sh): the 4 x wider W stream per output column pays from
+          // K = 640 on, and a multi-round grid wins even at 75 % fill of its last round; 128-row tiles for the 8 x 8 maps
+          if (nk >= 10 && (fills(t256) || t256 >= 512)) { tm = 2; sp = 1; }
+          else if (nk >= 20 && t128 >= 224 && t128 <= 256) { tm = 1; sp = 1; }
         } else if (!conv && nk >= 20) {
           if (fills(t256)) { tm = 2; sp = 1; }
         }
@@ -858,7 +866,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
         a.splits = (nk + a.nk_per_split - 1) / a.nk_per_split;
         a.slab = reinterpret_cast<float*>(ws);
       }
-      g_last_kernel = 300 + 10 * (geglu ? 2 : (conv ? 1 : 0)) + tm + (persist ? 4 : 0);
+      g_last_kernel = 300 + 10 * (geglu ? 2 : (conv ? 1 : 0)) + tm + (persist ? 4 : 0) + (lnf ? 2000 : 0);
       launch_gemm3<T>(a, geglu ? 2 : (conv ? 1 : 0), tm, batch, st, persist);
       HALLO_CHECK_LAUNCH();
       if (a.splits > 1) {

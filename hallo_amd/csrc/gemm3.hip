@@ -281,6 +281,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   }
 
   // ---- epilogue ----
+  const bool lnf = !CONV && p.ln_colsum != nullptr && p.ln_stats != nullptr && p.splits <= 1;
   const T* bias = reinterpret_cast<const T*>(p.bias);
   const T* bias2 = reinterpret_cast<const T*>(p.bias2);
   const T* res = p.residual ? reinterpret_cast<const T*>(p.residual) + zb * p.sR : nullptr;
@@ -320,10 +321,19 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
         const int gch = ps < 2 ? 8 + rc : 4 + rc;
         const bool lane_on = ps < 2 || rc < 4;
         const int n = n0 + wn * 80 + ps * 32 + rc * 4;
-        float bh[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0};
-        if (bias && lane_on && n < p.N) {
+        // value / gate = [rstd * (acc - mean * G[n])] + bias; the gate argument is scaled by s and the value by 1 / s for
+        // gelu_u (common.h): the factors ride in the constants
+        float bh[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0}, gh[4] = {0, 0, 0, 0}, gg[4] = {0, 0, 0, 0};
+        if (lane_on && n < p.N) {
+          if (bias) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { bh[j] = to_f32(bias[n + j]); bg[j] = to_f32(bias[p.N + n + j]); }
+            for (int j = 0; j < 4; ++j) { bh[j] = GELU_U_INV * to_f32(bias[n + j]); bg[j] = GELU_U_SCALE * to_f32(bias[p.N + n + j]); }
+          }
+          if (lnf) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_colsum + n), b = *reinterpret_cast<const f32x4*>(p.ln_colsum + p.N + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { gh[j] = a[j]; gg[j] = b[j]; }
+          }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -332,9 +342,18 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
           const f32x4 hv = *reinterpret_cast<const f32x4*>(tile + rr * 64 + ((rc ^ (rr & 15)) * 4));
           const f32x4 gv = *reinterpret_cast<const f32x4*>(tile + rr * 64 + ((gch ^ (rr & 15)) * 4));
           if (lane_on && m < p.M && n < p.N) {
+            float vs = GELU_U_INV, gs = GELU_U_SCALE, vc = 0.0f, gc = 0.0f;      // out = scale * acc + shift * G[n] + bias'
+            if (lnf) {
+              const float mean = p.ln_stats[2 * (long)m], rstd = p.ln_stats[2 * (long)m + 1];
+              vs *= rstd; gs *= rstd; vc = -mean * vs; gc = -mean * gs;
+            }
             V4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = from_f32<T>((hv[j] + bh[j]) * gelu_erf_f(gv[j] + bg[j]));
+            for (int j = 0; j < 4; ++j) {
+              const float hvv = __builtin_fmaf(vs, hv[j], __builtin_fmaf(vc, gh[j], bh[j]));
+              const float gu = __builtin_fmaf(gs, gv[j], __builtin_fmaf(gc, gg[j], bg[j]));
+              o[j] = from_f32<T>(hvv * gelu_u(gu));
+            }
             *reinterpret_cast<V4*>(C + (long)m * p.ldc + n) = o;
           }
         }
@@ -361,6 +380,12 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
       }
       float bcol[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (bias && !p.bias_per_row && n_ok && p.splits <= 1) ld8f(bias + n, p.bias_vec_ok, bcol);
+      float gcol[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (lnf && n_ok) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_colsum + n), b = *reinterpret_cast<const f32x4*>(p.ln_colsum + n + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gcol[j] = a[j]; gcol[4 + j] = b[j]; }
+      }
       put(acc[2 * ps][tm], 0);
       if (ps < 2) put(acc[2 * ps + 1][tm], 1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -381,6 +406,12 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
         float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         float t8[8];
         const float br = (bias && p.bias_per_row) ? to_f32(bias[m]) : 0.0f;
+        if (lnf) {       // fused LayerNorm: rstd * (acc - mean * G[n]) with the statistics of hallo_row_stats
+          const float mean = p.ln_stats[2 * (long)m], rstd = p.ln_stats[2 * (long)m + 1];
+          const float c1 = -mean * rstd;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(rstd, o[j], c1 * gcol[j]);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] += bcol[j] + br;
         if (bias2) {

@@ -187,7 +187,7 @@ def test_vae_mid_attention_full(dtype, report):
 # --------------------------------------------------------------------------------------------
 # gemm_rs.hip: the row-stationary kernel for K = 320 / 640 (A rows in registers, LayerNorm statistics computed in-kernel)
 def _took_rs(ops):
-    return (ops.get_option("last_gemm_kernel") % 1000) // 100 == 4
+    return (ops.get_option("last_gemm_kernel") % 1000) // 100 in (4, 5)       # gemm_rs.hip (K = 640) / gemm_rs2.hip (K = 320)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -208,8 +208,9 @@ def test_gemm_rs_layernorm_qkv(dtype, M, N, K, report):
     lead = (N // 3) // 32 * 32
     rpg = 4096 if M % 4096 == 0 else 0
     b2 = _rand((M // 4096, N), dtype, g) if rpg else None
-    # 73728 rows = 288 workgroups of 256 rows: the second round of 256 would be 12 % full -> stays on the tiled kernel
-    fused = M != 73728
+    # 73728 rows = 288 row blocks: gemm_rs2.hip shares the 32 blocks of the under-filled second round between 8 workgroups
+    # each (N slices), so the K = 320 case is fused too
+    fused = True
     assert (ops.ln_stats(x, N, 1e-5, bias2_rows_per_group=rpg, lead_cols=lead) is None) == fused
     out = ops.gemm(x, wf, bf, ln_colsum=cs, ln_eps=1e-5, lead_cols=lead, lead_alpha=0.25, bias2=b2, bias2_rows_per_group=rpg)
     assert _took_rs(ops) == fused, ops.get_option("last_gemm_kernel")
@@ -225,7 +226,7 @@ def test_gemm_rs_layernorm_qkv(dtype, M, N, K, report):
                        ln_stats=ops.row_stats(x, 1e-5))
         assert not _took_rs(ops)
     finally:
-        ops.set_option("gemm_rs", 1)
+        ops.set_option("gemm_rs", 2)
     _check(f"gemm_rs_ln_vs_tiled[{M},{N},{K}]", out, old.float(), dtype, report)
 
 
@@ -243,7 +244,7 @@ def test_gemm_rs_geglu(dtype, M, Cd, report):
     b = _rand((8 * Cd,), dtype, g, 0.1)
     wf, cs, bf = ops.fold_layernorm(gamma, beta, w, b)
     out = ops.gemm(x, wf, bf, geglu=True, ln_colsum=cs, ln_eps=1e-5, ln_stats=ops.ln_stats(x, 4 * Cd, 1e-5, geglu=True))
-    fused = M != 73728 and 8 * Cd <= 2560          # K = 640: 5120 rows of W exceed the kernel's LDS constants
+    fused = 8 * Cd <= 2560          # K = 640: 5120 rows of W exceed the kernel's LDS constants
     assert _took_rs(ops) == fused, ops.get_option("last_gemm_kernel")
     nh = torch.nn.functional.layer_norm(x.float(), (Cd,), gamma.float(), beta.float(), 1e-5)
     _check(f"gemm_rs_geglu_ln[{M},{Cd}]", out, ops_ref.geglu(nh, w, b), dtype, report)
@@ -273,9 +274,12 @@ def test_gemm_rs_plain_and_fallbacks(dtype, report):
     res = _rand((M, N), dtype, g)
     ops.gemm(a, w, b, residual=res)
     assert not _took_rs(ops)
-    ops.gemm(a[:16384], w, b)                        # 64 workgroups: three quarters of the CUs would idle
+    out = ops.gemm(a[:16384], w, b)                  # 64 row blocks: four workgroups per block, a quarter of N each
+    assert _took_rs(ops)
+    _check("gemm_rs_n_slices", out, ops_ref.linear(a[:16384], w, b), dtype, report)
+    ops.gemm(a[:4096], w, b)                         # below 8192 rows the tiled kernels' finer grid is used
     assert not _took_rs(ops)
-    assert ops.ln_stats(a[:16384], N, 1e-5) is not None
+    assert ops.ln_stats(a[:4096], N, 1e-5) is not None
     a2 = _rand((M, 1280), dtype, g)
     w2 = _rand((N, 1280), dtype, g, 1280 ** -0.5)
     ops.gemm(a2, w2, b)
