@@ -39,7 +39,12 @@ constexpr int A40_OFF_VB = A40_OFF_VA + 2 * A40_VA_TILE;     // 18432
 constexpr int A40_OFF_ONE = A40_OFF_VB + 2 * A40_VB_TILE;    // 20480: 16-byte pattern [1, 0, 0, 0, 0, 0, 0, 0]
 constexpr int A40_ONE_BYTES = 8192;                          // >= largest immediate of a K pad read (stage + t) + 16
 constexpr int A40_OFF_ZERO = A40_OFF_ONE + A40_ONE_BYTES;    // 28672
-constexpr int A40_ZERO_BYTES = 2048;                         // >= largest immediate of a V pad read + 8
+constexpr int A40_ZERO_BYTES = 2304;                         // >= largest immediate of a V pad read + 8 + A40_PAD_ZERO_SKEW
+// Bank skew of the constant operands of the plane-B transposing read.  Plane B, the ones pattern and the zeros all start at
+// bank 0 and are addressed with the same immediates, so the three addresses of one ds_read_b64_tr_b16 (8 lanes of V data,
+// the lanes of row 40, the zero lanes) met on the same banks: SQ_LDS_BANK_CONFLICT was 30 % of SQ_LDS_IDX_ACTIVE
+// (profiles/r2_attn_pmc.json).  The patterns repeat every 16 bytes, so the constants are simply read 64 / 128 bytes further.
+constexpr int A40_PAD_ONE_SKEW = 64, A40_PAD_ZERO_SKEW = 128;
 constexpr int A40_LDS = A40_OFF_ZERO + A40_ZERO_BYTES;       // 30720
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
@@ -197,9 +202,9 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   // row 4*hi + (i >> 2), 4 columns (i & 3)*4 of the group's 16
   const int gi = lane & 15, gdh = (lane >> 4) & 1;
   const lds_u8* const vbA = lds + A40_OFF_VA + (4 * hi + (gi >> 2)) * 64 + gdh * 32 + (gi & 3) * 8;
-  const lds_u8* const vbB = gdh ? lds + A40_OFF_ZERO
+  const lds_u8* const vbB = gdh ? lds + A40_OFF_ZERO + A40_PAD_ZERO_SKEW
                                 : ((gi & 3) < 2 ? lds + A40_OFF_VB + (4 * hi + (gi >> 2)) * 16 + (gi & 3) * 8
-                                                : ((gi & 3) == 2 ? lds + A40_OFF_ONE : lds + A40_OFF_ZERO));
+                                                : ((gi & 3) == 2 ? lds + A40_OFF_ONE + A40_PAD_ONE_SKEW : lds + A40_OFF_ZERO + A40_PAD_ZERO_SKEW));
 
   f32x16 oacc[NDB];
 #pragma unroll

@@ -52,7 +52,12 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   constexpr int NA = BM / 64;            // A slabs per wave per K step
   constexpr int NW = 5;                  // W slabs per wave per K step
   constexpr int NP = NA + NW;
-  constexpr int PPK = (NP + 3) / 4;      // DMA pieces issued per 16-deep k slice
+#ifndef G3_FRONT
+#define G3_FRONT 0
+#endif
+  // DMA pieces issued per 16-deep k slice: spread over the four slices of a K step, or (G3_FRONT, A/B build) front-loaded
+  // into the first two so that the last piece has half a step to land before the next step's vmcnt(0)
+  constexpr int PPK = G3_FRONT ? (NP + 1) / 2 : (NP + 3) / 4;
   constexpr int SLOT = (BM + G3_BN) * G3_BK;
   // persistent mode keeps slot 1 clear of the 64 KB epilogue scratch at the start of the array
   constexpr int SLOT_STRIDE = (PERSIST && SLOT < 32768) ? 32768 : SLOT;
@@ -247,7 +252,14 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
         for (int j = 0; j < TM; ++j) acc[i][j] = Vec<T>::mfma32(fw[ks & 1][i], fa[ks & 1][j], acc[i][j]);
       // spread this slice's DMA issues between its MFMAs (an LDS-DMA issue costs ~60-100 cycles of this wave's
       // issue slot; behind an MFMA it is free)
-      if (np == 3) {
+      if (np >= 4) {
+        // np pieces between NMF MFMAs: MFMA groups of NMF / (np + 1)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          if (q < np) { __builtin_amdgcn_sched_group_barrier(0x008, NMF / (PPK + 1) > 0 ? NMF / (PPK + 1) : 1, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+      } else if (np == 3) {
         __builtin_amdgcn_sched_group_barrier(0x008, NMF / 4, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, NMF / 4, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, NMF / 4, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);

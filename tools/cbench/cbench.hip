@@ -154,6 +154,7 @@ struct Timer {
     return ms * 1000.0f / iters;      // us
   }
 };
+static int g_rounds = 5, g_iters = 10;      // timing loops; "quick" (PMC passes) -> 1 x 3
 static float median(std::vector<float> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -256,10 +257,10 @@ static int cmd_attn_time(int argc, char** argv) {
       const double flop = 4.0 * C * c.L * c.B * ((double)c.L * (c.bank ? 2 : 1));
       std::vector<std::vector<float>> t(variants.size());
       for (size_t i = 0; i < variants.size(); ++i) { HK(hallo_set_option("attn40", variants[i])); tm.run([&] { HK(hallo_attention(&d, nullptr)); }, 3); }
-      for (int r = 0; r < 5; ++r)
+      for (int r = 0; r < g_rounds; ++r)
         for (size_t i = 0; i < variants.size(); ++i) {
           HK(hallo_set_option("attn40", variants[i]));
-          t[i].push_back(tm.run([&] { HK(hallo_attention(&d, nullptr)); }, 10));
+          t[i].push_back(tm.run([&] { HK(hallo_attention(&d, nullptr)); }, g_iters));
         }
       for (size_t i = 0; i < variants.size(); ++i) {
         const float us = median(t[i]);
@@ -332,6 +333,10 @@ static void run_gemm_case(const GemmOpts& g, Timer& tm) {
   d.A = A; d.B = g.ln ? Wf : W; d.C = Cc; d.M = g.M; d.N = g.N; d.K = g.K; d.lda = g.K; d.ldb = g.K; d.ldc = g.N; d.batch = 1;
   d.bias = g.ln ? bf : bias; d.residual = R; d.ldr = g.N; d.alpha = 1.0f; d.geglu = g.geglu; d.dtype = dt; d.lead_alpha = 1.0f;
   if (g.ln) { d.ln_colsum = cs; d.ln_eps = 1e-5f; }
+  static void* ws = nullptr;                       // split-K scratch, as hallo_amd/ops.py hands one to every GEMM
+  const long ws_bytes = 256L << 20;
+  if (!ws) CK(hipMalloc(&ws, ws_bytes));
+  d.workspace = ws; d.workspace_bytes = ws_bytes;
   const bool fused_stats = g.ln && hallo_gemm_fuses_row_stats(g.M, g.N, g.K, g.geglu, 0, 0);
   if (g.ln && !fused_stats) d.ln_stats = stats;
   auto launch = [&] {
@@ -361,7 +366,7 @@ static void run_gemm_case(const GemmOpts& g, Timer& tm) {
     CK(hipFree(ref));
   }
   tm.run(launch, 3);
-  std::vector<float> t; for (int r = 0; r < 5; ++r) t.push_back(tm.run(launch, 10));
+  std::vector<float> t; for (int r = 0; r < g_rounds; ++r) t.push_back(tm.run(launch, g_iters));
   const float us = median(t);
   const double flop = 2.0 * g.M * (double)wrows * g.K, bytes = 2.0 * ((double)g.M * g.K + (double)wrows * g.K + (double)g.M * g.N * (g.res ? 2 : 1));
   printf("gemm M=%d N=%d K=%d%s%s%s dt=%s rs=%d variant=%d rsdbg=%d kernel=%d fused_stats=%d: %.1f us  %.1f TFLOP/s  %.0f GB/s  rel_l2(first rows)=%.2e nan=%ld nondet=%d\n",
@@ -409,6 +414,7 @@ static int cmd_gemm_suite(int argc, char** argv) {
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: cbench attn-det | attn-time [v,v,..] | gemm M N K [flags] | gemm-suite\n"); return 64; }
   CK(hipSetDevice(0));
+  if (getenv("CBENCH_QUICK")) { g_rounds = 1; g_iters = 3; }
   printf("cbench: libhallo_amd ABI %d\n", hallo_abi_version());
   std::string cmd = argv[1];
   if (cmd == "attn-det") return cmd_attn_det(argc - 2, argv + 2);
