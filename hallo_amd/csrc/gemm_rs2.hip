@@ -38,6 +38,9 @@ constexpr int R2_SUB = 5;                                    // [64 rows][64 k] 
 constexpr int R2_SUB_BYTES = 64 * 128;
 constexpr int R2_CHUNK_BYTES = R2_SUB * R2_SUB_BYTES;        // 40960
 constexpr int R2_RING = 3;
+#ifndef R2_EPI_REGIONS
+#define R2_EPI_REGIONS 8     // of the 10 two-k16 regions of a step, how many carry the previous pair's epilogue (A/B: 4)
+#endif
 constexpr int R2_MAX_WROWS = 2560;
 constexpr int R2_CONST_N = R2_MAX_WROWS + 64;                // + one pair of slack: a partial last pair indexes past N
 constexpr int R2_OFF_BIAS = R2_RING * R2_CHUNK_BYTES;        // fp32 [R2_CONST_N]
@@ -266,10 +269,10 @@ __global__ __launch_bounds__(512, 2) void gemm_rs2_kernel(const GemmArgs p) {
           else acc_cur[nb] = Vec<T>::mfma32(fr[k % 3][nb], af[k], k == 0 ? zero16 : acc_cur[nb]);
         }
       }
-      if constexpr (PREV && R < 8 && !(ABL & 2)) {
-        constexpr int PER = NELEM / 8;
+      if constexpr (PREV && R < R2_EPI_REGIONS && !(ABL & 2)) {
+        constexpr int PER = NELEM / R2_EPI_REGIONS;
         static_for<0, PER>([&](auto jc) { epi_elem(std::integral_constant<int, R * PER + decltype(jc)::value>{}, acc_prev, n0p, bv, bg); });
-        constexpr int SLICE = GEGLU ? 7 : 3;
+        constexpr int SLICE = (GEGLU ? 56 : 24) / R2_EPI_REGIONS;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
