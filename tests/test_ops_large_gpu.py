@@ -284,3 +284,32 @@ def test_gemm_rs_plain_and_fallbacks(dtype, report):
     w2 = _rand((N, 1280), dtype, g, 1280 ** -0.5)
     ops.gemm(a2, w2, b)
     assert not _took_rs(ops)
+
+
+# --------------------------------------------------------------------------------------------
+# gemm3.hip with the LayerNorm epilogue (round 2): LayerNorm-fused GEGLU / projections with K >= 640 on the big tile
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Cd,geglu", [(4096, 1280, True), (16384, 640, True), (4608, 1280, False), (1024, 1280, True)])
+def test_gemm_big_tile_layernorm(dtype, M, Cd, geglu, report):
+    """FeedForward net.0 (GEGLU, norm3 folded in) at the 16 x 16 / 32 x 32 / 8 x 8-latent levels and the motion module's fused
+    q|k|v at 16 x 16 (18 frames): the statistics come from hallo_row_stats, the big tile's epilogue applies
+    rstd * (acc - mean * G[n]) + bias; value / gate through gelu_u.  vs the fp32 expression."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(3 * M + Cd)
+    x = _rand((M, Cd), dtype, g) * 1.1 + 0.2
+    gamma = (1.0 + 0.1 * torch.randn((Cd,), generator=g)).to(dtype).to(_dev())
+    beta = _rand((Cd,), dtype, g, 0.1)
+    N = 8 * Cd if geglu else 3 * Cd
+    w = _rand((N, Cd), dtype, g, Cd ** -0.5)
+    b = _rand((N,), dtype, g, 0.1)
+    wf, cs, bf = ops.fold_layernorm(gamma, beta, w, b)
+    st = ops.ln_stats(x, N // 2 if geglu else N, 1e-5, geglu=geglu)
+    assert st is not None                                  # K != 320: no row-stationary kernel, the caller computes the statistics
+    out = ops.gemm(x, wf, bf, geglu=geglu, ln_colsum=cs, ln_eps=1e-5, ln_stats=st)
+    code = ops.get_option("last_gemm_kernel")
+    assert code // 1000 == 2 and (code % 1000) // 100 == 3, code        # 23xx: gemm3_kernel with the LayerNorm epilogue
+    nh = torch.nn.functional.layer_norm(x.float(), (Cd,), gamma.float(), beta.float(), 1e-5)
+    ref = ops_ref.geglu(nh, w, b) if geglu else nh @ w.float().t() + b.float()
+    _check(f"gemm3_ln[{M},{Cd},{'geglu' if geglu else 'qkv'}]", out, ref, dtype, report)
