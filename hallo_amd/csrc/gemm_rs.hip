@@ -19,8 +19,11 @@
 //     counted vmcnt and ONE barrier per chunk (16 / 8 MFMAs per wave per barrier);
 //   * swapped operands (D = W . A^T): a lane owns an output row, the epilogue scalars of the row (mean, rstd) are lane-local,
 //     bias / column sums come from LDS, two 8-byte groups are merged with one v_permlane32_swap into 16-byte stores.
-// What bounds these GEMMs is the L2 -> LDS fabric, not HBM and not the matrix pipe: every workgroup streams the WHOLE of W
-// past its rows, so the fabric carries (M / rows per workgroup) x |W| bytes.  Measured: a 128-row workgroup (two per CU) ran
+// (Round-2 correction, tools/cbench `rsdbg` ablations: what held THIS kernel was its epilogue -- q|k|v 74 us full / 43 without
+// epilogue / 35 MFMA loop alone, GEGLU 180 / 111 / 86 -- not the fabric as the paragraph below concluded.  gemm_rs2.hip, which
+// takes the K = 320 problems now, turns the loops round so that the epilogue interleaves with the next pair's MFMAs; this
+// kernel remains for K = 640, where 160 registers of A fragments leave no room for a second accumulator set.)
+// Every workgroup streams the WHOLE of W past its rows, so the L2 -> LDS fabric carries (M / rows per workgroup) x |W| bytes.  Measured: a 128-row workgroup (two per CU) ran
 // the 65536 x 960 x 320 K loop in 46-49 us = 314 MB at 6.8 TB/s from L2 whatever the ring depth, chunk size or fragment-read
 // schedule (MFMA floor 20 us); the tiled 128 x 128 kernel moves 614 MB for the same problem.  So the workgroup is made as
 // tall as the register file allows: 8 waves x 32 rows = 256 rows share ONE W stream (157 MB), one workgroup per CU.  The two

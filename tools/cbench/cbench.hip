@@ -245,8 +245,10 @@ static int cmd_attn_time(int argc, char** argv) {
   const AttnCase cases[] = {{"L0 self+bank 16x4096x(4096+4096)", 16, 4096, 1}, {"L0 audio-block self 16x4096x4096", 16, 4096, 0},
                             {"256^2 L0 self+bank 8x1024x(1024+1024)", 8, 1024, 1}};
   Timer tm;
+  const char* only_case = getenv("CBENCH_CASE");      // PMC passes: one shape (0..2), bf16 only
   for (int dt = 1; dt >= 0; --dt)
     for (const AttnCase& c : cases) {
+      if (only_case && (dt != 1 || (int)(&c - cases) != atoi(only_case))) continue;
       const long nq = (long)c.B * c.L * 3 * C, nb = (long)c.L * 2 * C, no = (long)c.B * c.L * C;
       uint16_t* qkv = dalloc<uint16_t>(nq); uint16_t* bkv = dalloc<uint16_t>(nb); uint16_t* o = dalloc<uint16_t>(no);
       fill(qkv, nq, 11 + dt, 1.0f, 0.0f, dt); fill(bkv, nb, 23 + dt, 1.0f, 0.0f, dt);
