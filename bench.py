@@ -424,12 +424,21 @@ def main():
         elapsed = float(t.item())
 
     total_frames = world * args.steps * Fr
+    # which BASELINE.json configuration the flags describe (the metric is quoted on configs[1]; anything else is labelled as such)
+    if (S, Fr) == (512, 16) and args.ddim_steps == 25 and args.guidance <= 1.0 and not args.fp8_proj:
+        cfg_name = "BASELINE.json configs[1]"
+    elif (S, Fr) == (512, 16) and args.ddim_steps == 40 and args.guidance > 1.0 and not args.fp8_proj:
+        cfg_name = "BASELINE.json configs[2]"
+    elif (S, Fr) == (768, 24) and args.ddim_steps == 40 and args.fp8_proj:
+        cfg_name = "BASELINE.json configs[4] (per-GPU workload)"
+    else:
+        cfg_name = "NOT a BASELINE.json configuration (custom flags)"
     out = {
         "metric": "generated frames/sec at 512x512, 16-frame window, 25 DDIM steps",
         "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype + ("+fp8proj" if args.fp8_proj else ""), "data": "synthetic (random-init weights of the reference architecture, synthetic clip inputs)",
-        "config": {"workload": f"BASELINE.json configs[{2 if args.guidance > 1.0 else 1}] per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
+        "config": {"workload": f"{cfg_name} per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
                                f"steps, guidance {args.guidance} ({'CFG, B=2' if args.guidance > 1 else 'no CFG, B=1'}), "
                                "ReferenceNet + VAE encode/decode + D2H inside the timed region",
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (
