@@ -318,6 +318,9 @@ def main():
     ap.add_argument("--fp8-proj", action="store_true",
                     help="BASELINE.json configs[4]'s projection variant: q|k|v / out projections of the denoising UNet's "
                          "self-attentions on the fp8 MFMA path (csrc/fp8.hip); the JSON line then says dtype bf16+fp8proj")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="A/B: launch every kernel of every UNet evaluation from the host (round-2 behaviour) instead of replaying "
+                         "the hipGraph captured in the warm-up clip (FaceAnimatePipeline(use_graph=True))")
     ap.add_argument("--gather", default=None, choices=["u8", "f32"],
                     help="N > 1: what the per-wave all-gather moves -- u8 (default): the frames converted to the uint8 video bytes on "
                          "the device (hallo_frames_to_uint8 = hallo/utils/util.py:308-312, 12.6 MB per rank at 512x512x16f); f32: "
@@ -364,6 +367,8 @@ def main():
         pipe, audioproj = build_pipeline(dev, dtype)
         if args.fp8_proj:
             pipe.denoising_unet.set_fp8_projections(True)
+        # one hipGraph of the UNet evaluation, captured during the warm-up clip, replayed for steps 1.. of every clip
+        pipe.use_graph = not args.no_graph and args.warmup > 0
     from hallo_amd.animate.clip_parallel import gather_wave
     gather_u8 = world > 1 and (args.gather or ("f32" if dry else "u8")) == "u8"
     # rank 0 receives the whole wave (one clip per rank) and copies ALL of it to the host
@@ -441,6 +446,7 @@ def main():
         "config": {"workload": f"{cfg_name} per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
                                f"steps, guidance {args.guidance} ({'CFG, B=2' if args.guidance > 1 else 'no CFG, B=1'}), "
                                "ReferenceNet + VAE encode/decode + D2H inside the timed region",
+                   "launch": "hipGraph replay of the UNet evaluation (steps 1.. of every clip)" if (not dry and pipe.use_graph) else "eager",
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (
                        f" + RCCL all-gather of the decoded frames ({'uint8 video bytes' if gather_u8 else 'fp32'})" if world > 1 else "")},
     }
@@ -453,6 +459,7 @@ def main():
     elif rank == 0 and not args.no_profile:
         prof = OpProfiler()
         prof.install(dtype)
+        pipe.use_graph = False              # the instrumented clip brackets every launch with events: eager
         run(inputs[-1], exchange=False)     # rank 0 alone: the instrumented clip must not enter a collective
         fam = prof.summary()
         prof.remove()

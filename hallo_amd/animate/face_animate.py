@@ -12,7 +12,10 @@ Execution plan (not the reference's):
     kernel for CFG combine + DDIM update on fp32 latents that also writes the next UNet input;
     timestep / alpha lookups are host integers, so there is no device sync inside the loop
     (the reference syncs twice per step: CPU `alphas_cumprod[t]` with a device `t`, and the CPU `uc_mask`);
-  * decode: all F frames as one batch, clamp + NCHW fp32 conversion fused, one D2H copy.
+  * decode: all F frames as one batch, clamp + NCHW fp32 conversion fused, one D2H copy;
+  * `use_graph=True`: the UNet evaluation is captured ONCE per (geometry, batch, dtype) as a hipGraph and replayed for steps
+    1.. of every clip (step 0 of a clip runs eagerly and refreshes the per-clip constants in place); the timestep lives in
+    a device tensor, latents / mask feature / constants in buffers that keep their addresses from clip to clip.
 
 Deviation from the reference, on purpose: `guidance_scale <= 1` works (the reference doubles the audio
 tensor unconditionally, face_animate.py:377-379, and then dies in the audio cross-attention -- SURVEY F5);
@@ -34,12 +37,38 @@ class FaceAnimatePipelineOutput:
     videos: torch.Tensor
 
 
+class StepGraph:
+    """Static buffers + the captured hipGraph of one `UNet3DConditionModel.forward_tokens` call.  ~690 kernel launches per
+    evaluation go through ctypes at 3-4 us of host time each; behind the sub-10-us kernels of the 8x8 / 16x16 levels the GPU
+    waits for the host (3 % of a clip in launch gaps, profiles/r2_bench_launch_gaps.json).  A replay is one host call."""
+
+    def __init__(self, B, Fr, L, C0, device, dtype):
+        self.x_in = torch.zeros((B * Fr, L, 8), device=device, dtype=dtype)
+        self.mask_cond = torch.zeros((B * Fr, L, C0), device=device, dtype=dtype)
+        self.t_dev = torch.zeros((B,), device=device, dtype=torch.float32)
+        self.cache = ClipCache()
+        self.graph, self.out = None, None
+        self.replays = 0
+
+    def capture(self, fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.out = fn()
+        self.graph = g
+
+
 class FaceAnimatePipeline:
-    def __init__(self, vae, reference_unet, denoising_unet, face_locator, image_proj, scheduler):
+    def __init__(self, vae, reference_unet, denoising_unet, face_locator, image_proj, scheduler, use_graph=False):
         self.vae, self.reference_unet, self.denoising_unet = vae, reference_unet, denoising_unet
         self.face_locator, self.image_proj, self.scheduler = face_locator, image_proj, scheduler
         self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
         self.timings = {}
+        self.use_graph = use_graph
+        self._graphs = {}
+
+    def reset_graphs(self):
+        """Drop every captured UNet graph (after changing a kernel option with ops.set_option, or to release their memory)."""
+        self._graphs.clear()
 
     def to(self, device=None, dtype=None):
         for m in (self.vae, self.reference_unet, self.denoising_unet, self.face_locator, self.image_proj):
@@ -107,7 +136,16 @@ class FaceAnimatePipeline:
         C_lat = den.in_channels
         lat5 = self.prepare_latents(1, C_lat, width, height, Fr, dt, dev, generator, latents)
         lat = lat5[0].permute(1, 2, 3, 0).reshape(Fr * L, C_lat).float().contiguous()
-        x_in = torch.zeros((B * Fr, L, 8), device=dev, dtype=dt)
+        C0 = den.config.block_out_channels[0]
+        sg = None
+        if self.use_graph:
+            ms_key = None if motion_scale is None else tuple(float(m) for m in motion_scale)
+            key = (B, Fr, h, w, dt, str(dev), ref_image.shape[1] if ref_image.dim() == 5 else ref_image.shape[0], ms_key,
+                   bool(getattr(den, "fp8_projections", False)), den.prepare_epoch)
+            sg = self._graphs.get(key)
+            if sg is None:
+                sg = self._graphs[key] = StepGraph(B, Fr, L, C0, dev, dt)
+        x_in = sg.x_in if sg is not None else torch.zeros((B * Fr, L, 8), device=dev, dtype=dt)
         x_in.view(B, Fr * L, 8)[:, :, :C_lat] = lat.to(dt)
 
         # -- reference + motion frames -> latents (face_animate.py:332-336)
@@ -119,8 +157,8 @@ class FaceAnimatePipeline:
         # -- face locator on one frame, broadcast over the F identical frames (face_animate.py:339-343)
         fm = self._image_tokens(face_mask.reshape(-1, *face_mask.shape[-3:])[:1], dt)
         fea, _, _ = self.face_locator.forward_tokens(fm, 1, height, width)          # [1, L, C0]
-        C0 = fea.shape[-1]
-        mask_cond = torch.zeros((B, Fr, L, C0), device=dev, dtype=dt)
+        assert fea.shape[-1] == C0
+        mask_cond = sg.mask_cond.view(B, Fr, L, C0) if sg is not None else torch.zeros((B, Fr, L, C0), device=dev, dtype=dt)
         mask_cond[B - 1] = fea[0]                                                   # uncond half stays zero
         mask_cond = mask_cond.view(B * Fr, L, C0)
 
@@ -132,21 +170,35 @@ class FaceAnimatePipeline:
             audio = torch.cat([torch.zeros_like(audio), audio], dim=0)
         audio = audio.reshape(B * Fr, audio.shape[-2], audio.shape[-1]).contiguous()
 
-        cache = ClipCache()
+        if sg is not None:
+            cache = sg.cache
+            cache.begin_clip()          # step 0 (eager) refreshes the per-clip constants inside their old storage
+        else:
+            cache = ClipCache()
         for i, t in enumerate(self.progress_bar(timesteps)):
             if i == 0:
                 # ReferenceNet write pass on [ref, m1, m2] (x2 under CFG) at t = 0 (face_animate.py:386-395)
                 refnet.written_banks = refnet.forward_tokens(ref_lat.repeat(B, 1, 1), 0, enc, h, w)
                 reader.update(writer)
-            v = den.forward_tokens(x_in, int(t), enc, den.reference_bank, audio, mask_cond, masks, motion_scale, B, Fr,
-                                   h, w, do_cfg, cache)
+            if sg is not None and i > 0:
+                sg.t_dev.fill_(float(t))
+                if sg.graph is None:
+                    sg.capture(lambda: den.forward_tokens(x_in, sg.t_dev, enc, den.reference_bank, audio, mask_cond, masks,
+                                                          motion_scale, B, Fr, h, w, do_cfg, cache))
+                sg.graph.replay()
+                sg.replays += 1
+                v = sg.out
+            else:
+                v = den.forward_tokens(x_in, int(t), enc, den.reference_bank, audio, mask_cond, masks, motion_scale, B, Fr,
+                                       h, w, do_cfg, cache)
             a_t, a_p = self.scheduler.step_alphas(t)
             ops.cfg_ddim_step(v, lat, x_in, Fr * L, C_lat, do_cfg, guidance_scale, a_t, a_p, self.scheduler.step_mode)
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, lat.view(Fr, h, w, C_lat).permute(3, 0, 1, 2).unsqueeze(0).to(dt))
         reader.clear()
         writer.clear()
-        cache.clear()
+        if sg is None:
+            cache.clear()
         if not decode:
             return lat.view(Fr, h, w, C_lat).permute(3, 0, 1, 2).unsqueeze(0)
         if output_type == "device":

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhallo_amd.so")
-SOURCES = ["gemm.hip", "gemm3.hip", "gemm_rs.hip", "gemm_rs2.hip", "attention.hip", "attention40.hip", "fp8.hip", "fused_xattn.hip", "norm_elementwise.hip", "wav2vec.hip"]
+SOURCES = ["gemm.hip", "gemm3.hip", "gemm_rs.hip", "gemm_rs2.hip", "gemm_ff.hip", "attention.hip", "attention40.hip", "fp8.hip", "fused_xattn.hip", "norm_elementwise.hip", "wav2vec.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_args.h"), os.path.join(CSRC, "attn_args.h"), os.path.join(HERE, "..", "include", "hallo_amd.h")]
 
 
@@ -40,6 +40,8 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + HEADERS):
             cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+            if os.environ.get("HALLO_ABLATIONS") == "1":      # timing-ablation switches of the row-stationary GEMMs (tools/cbench)
+                cmd.insert(1, "-DHALLO_ABLATIONS")
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)

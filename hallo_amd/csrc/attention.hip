@@ -666,8 +666,13 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
   a.rs_hdiv = d->o_rowscale_head_div > 0 ? d->o_rowscale_head_div : d->heads;
   a.rs_stride = d->o_rowscale_stride;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (g_attn40 && d->head_dim == 40 && d->q_prescaled != 0 && (d->dtype == DT_F16 || d->dtype == DT_BF16) &&
-      !(d->o_rs & 7) && !(d->o_bs & 7) && !(reinterpret_cast<uintptr_t>(d->o) & 15))          // 16-byte output stores
+  // attention40.hip stages K / V with 16-byte LDS-DMA (buffer addressing drops misaligned low address bits) and stores 16
+  // bytes per lane: every K / V base, row and batch stride and the output must be 16-byte aligned, else the generic kernel
+  const auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+  const bool kv_aligned = al16(d->k1) && al16(d->v1) && !((d->k1_bs | d->v1_bs | d->k1_rs | d->v1_rs) & 7) &&
+                          (!d->k2 || (al16(d->k2) && al16(d->v2) && !((d->k2_bs | d->v2_bs | d->k2_rs | d->v2_rs) & 7)));
+  if (g_attn40 && d->head_dim == 40 && d->q_prescaled != 0 && (d->dtype == DT_F16 || d->dtype == DT_BF16) && kv_aligned &&
+      !(d->o_rs & 7) && !(d->o_bs & 7) && al16(d->o))
     return launch_attn40(a, d->dtype, st);          // attention40.hip: LDS-DMA staging + transposing V reads
   if (d->dtype == DT_F16) return launch_attn<_Float16>(a, d->head_dim, d->q_prescaled != 0, st);
   if (d->dtype == DT_BF16) return launch_attn<__bf16>(a, d->head_dim, d->q_prescaled != 0, st);

@@ -1023,6 +1023,8 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
 
 extern "C" int hallo_set_option_norm(const char* name, int value);   // norm_elementwise.hip
 
+static int g_rs_dbg_value = 0;
+
 extern "C" int hallo_get_option_attn(const char* name);   // attention.hip
 
 extern "C" int hallo_get_option(const char* name) {
@@ -1032,6 +1034,8 @@ extern "C" int hallo_get_option(const char* name) {
   if (!strcmp(name, "v3_min_tiles")) return g_v3_min_tiles;
   if (!strcmp(name, "last_gemm_kernel")) return g_last_kernel;
   if (!strcmp(name, "gemm_rs")) return g_gemm_rs;
+  if (!strcmp(name, "gemm_rs_dbg")) return g_rs_dbg_value;
+  if (!strcmp(name, "ff_fused")) return ff_fused_variant();
   return hallo_get_option_attn(name);
 }
 
@@ -1042,6 +1046,15 @@ extern "C" int hallo_set_option(const char* name, int value) {
   if (!strcmp(name, "conv_fast")) { if (value < 0 || value > 1) return -22; g_conv_fast = value; return 0; }
   if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }
   if (!strcmp(name, "gemm_rs")) { if (value < 0 || value > 2) return -22; g_gemm_rs = value; return 0; }
-  if (!strcmp(name, "gemm_rs_dbg")) { set_gemm_rs_dbg(value); set_gemm_rs2_dbg(value); return 0; }
+  if (!strcmp(name, "ff_fused")) { if (value < 0 || value > 2) return -22; set_ff_fused_variant(value); return 0; }
+  if (!strcmp(name, "gemm_rs_dbg")) {
+    // timing ablations of the row-stationary kernels (no stores / no epilogue: WRONG results): only a library built with
+    // -DHALLO_ABLATIONS (HALLO_ABLATIONS=1 python -m hallo_amd.build, what tools/cbench uses) accepts a non-zero value
+#ifndef HALLO_ABLATIONS
+    if (value != 0) return -22;
+#endif
+    if (value < 0 || value > 7) return -22;
+    g_rs_dbg_value = value; set_gemm_rs_dbg(value); set_gemm_rs2_dbg(value); return 0;
+  }
   return hallo_set_option_norm(name, value);
 }

@@ -52,4 +52,8 @@ bool gemm_rs2_eligible(const GemmArgs& a, bool conv, bool geglu, int batch);
 template <typename T> int launch_gemm_rs2(const GemmArgs& a, bool geglu, hipStream_t st);
 void set_gemm_rs2_dbg(int v);
 
+// gemm_ff.hip: fused LayerNorm -> GEGLU -> net[2] -> + residual for C = 320 (hallo_ff320)
+int ff_fused_variant();
+void set_ff_fused_variant(int v);
+
 }  // namespace hallo

@@ -303,20 +303,25 @@ static int g_rs_dbg = 0;      // hallo_set_option("gemm_rs_dbg", bits): timing a
 void set_gemm_rs_dbg(int v) { g_rs_dbg = v; }
 
 template <typename T, int K16, int NB, bool G, bool L>
-static void launch_rs_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
-  static bool attr_done = false;       // the kernel needs more than the default 64 KB of dynamic LDS
-  if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rs_kernel<T, K16, NB, G, L>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
-    attr_done = true;
+static int launch_rs_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  static bool attr_done[64] = {};    // per device: the opt-in to > 64 KB of dynamic LDS belongs to the device's function
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -19;
+  if (!attr_done[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rs_kernel<T, K16, NB, G, L>), hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS) != hipSuccess)
+      return -12;
+    attr_done[dev] = true;
   }
   hipLaunchKernelGGL((gemm_rs_kernel<T, K16, NB, G, L>), grid, dim3(512), RS_LDS, st, a, g_rs_dbg);
+  return 0;
 }
 
 template <typename T>
 int launch_gemm_rs(const GemmArgs& a, bool geglu, hipStream_t st) {
   const bool lnf = a.ln_colsum != nullptr;
   dim3 grid((a.M + 255) / 256);
-#define HALLO_RS(K16, NB, G, L) launch_rs_one<T, K16, NB, G, L>(a, grid, st)
+  int rc = 0;
+#define HALLO_RS(K16, NB, G, L) rc = launch_rs_one<T, K16, NB, G, L>(a, grid, st)
   if (a.K == 320) {
     if (geglu) { if (lnf) HALLO_RS(20, 4, true, true); else HALLO_RS(20, 4, true, false); }
     else { if (lnf) HALLO_RS(20, 4, false, true); else HALLO_RS(20, 4, false, false); }
@@ -325,6 +330,7 @@ int launch_gemm_rs(const GemmArgs& a, bool geglu, hipStream_t st) {
     else { if (lnf) HALLO_RS(40, 2, false, true); else HALLO_RS(40, 2, false, false); }
   }
 #undef HALLO_RS
+  if (rc) return rc;
   HALLO_CHECK_LAUNCH();
   return 0;
 }

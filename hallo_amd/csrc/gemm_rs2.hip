@@ -341,13 +341,17 @@ static int g_rs2_dbg = 0;
 void set_gemm_rs2_dbg(int v) { g_rs2_dbg = v; }
 
 template <typename T, bool G, bool L, int ABL>
-static void launch_rs2_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rs2_kernel<T, G, L, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, R2_LDS);
-    attr_done = true;
+static int launch_rs2_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  static bool attr_done[64] = {};    // per device: the opt-in to > 64 KB of dynamic LDS belongs to the device's function
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -19;
+  if (!attr_done[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rs2_kernel<T, G, L, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, R2_LDS) != hipSuccess)
+      return -12;
+    attr_done[dev] = true;
   }
   hipLaunchKernelGGL((gemm_rs2_kernel<T, G, L, ABL>), grid, dim3(512), R2_LDS, st, a);
+  return 0;
 }
 
 template <typename T>
@@ -358,16 +362,21 @@ int launch_gemm_rs2(const GemmArgs& a0, bool geglu, hipStream_t st) {
   rs2_grid(a.M, (a.N + (geglu ? 31 : 63)) / (geglu ? 32 : 64), &full, &slices, &nwg);
   a.tiles_m = full; a.tiles_n = slices;
   dim3 grid(nwg);
-  if (g_rs2_dbg && lnf) {          // ablations exist for the LayerNorm-fused forms only
+  int rc = 0;
+#ifdef HALLO_ABLATIONS
+  if (g_rs2_dbg && lnf) {          // timing ablations (wrong results) exist for the LayerNorm-fused forms only
     const int abl = g_rs2_dbg & 7;
     if (geglu) {
-      if (abl == 1) launch_rs2_one<T, true, true, 1>(a, grid, st);
-      else if (abl == 5) launch_rs2_one<T, true, true, 5>(a, grid, st);
-      else launch_rs2_one<T, true, true, 2>(a, grid, st);
+      if (abl == 1) rc = launch_rs2_one<T, true, true, 1>(a, grid, st);
+      else if (abl == 5) rc = launch_rs2_one<T, true, true, 5>(a, grid, st);
+      else rc = launch_rs2_one<T, true, true, 2>(a, grid, st);
     }
-    else { if (abl == 1) launch_rs2_one<T, false, true, 1>(a, grid, st); else launch_rs2_one<T, false, true, 2>(a, grid, st); }
-  } else if (geglu) { if (lnf) launch_rs2_one<T, true, true, 0>(a, grid, st); else launch_rs2_one<T, true, false, 0>(a, grid, st); }
-  else { if (lnf) launch_rs2_one<T, false, true, 0>(a, grid, st); else launch_rs2_one<T, false, false, 0>(a, grid, st); }
+    else { if (abl == 1) rc = launch_rs2_one<T, false, true, 1>(a, grid, st); else rc = launch_rs2_one<T, false, true, 2>(a, grid, st); }
+  } else
+#endif
+  if (geglu) { if (lnf) rc = launch_rs2_one<T, true, true, 0>(a, grid, st); else rc = launch_rs2_one<T, true, false, 0>(a, grid, st); }
+  else { if (lnf) rc = launch_rs2_one<T, false, true, 0>(a, grid, st); else rc = launch_rs2_one<T, false, false, 0>(a, grid, st); }
+  if (rc) return rc;
   HALLO_CHECK_LAUNCH();
   return 0;
 }

@@ -126,6 +126,9 @@ SYMBOLS = {
     "hallo_gemm_fuses_row_stats": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "hallo_face_xattn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
+    "hallo_ff320_pack_bytes": (C.c_int64, []),
+    "hallo_ff320": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                              C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "hallo_frames_to_uint8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "hallo_w2v_conv0_workspace": (C.c_int64, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     "hallo_w2v_conv0_gn_gelu": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

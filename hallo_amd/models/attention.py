@@ -28,10 +28,15 @@ from .layers import Attention, Conv1x1, FeedForward, LayerNorm
 class ClipCache:
     """Per-clip store of step-invariant tensors, keyed by (module id, tag).  Owned by the pipeline
     (or absent: then everything is recomputed per call, which is what a bare
-    `UNet3DConditionModel.forward` drop-in call does)."""
+    `UNet3DConditionModel.forward` drop-in call does).
+
+    `begin_clip()` (graph mode, hallo_amd/animate/face_animate.py) keeps the entries of the previous clip as STORAGE: the
+    first `get` of a key in the new clip computes the new value and copies it INTO the old tensors, so the addresses a
+    captured hipGraph of the UNet evaluation reads stay valid from clip to clip."""
 
     def __init__(self):
         self._d = {}
+        self._stale = set()
 
     def get(self, mod, tag, make):
         k = (id(mod), tag)
@@ -39,10 +44,31 @@ class ClipCache:
         if v is None:
             v = make()
             self._d[k] = v
+        elif k in self._stale:
+            _copy_into(v, make())
+            self._stale.discard(k)
         return v
+
+    def begin_clip(self):
+        self._stale = set(self._d)
 
     def clear(self):
         self._d.clear()
+        self._stale.clear()
+
+
+def _copy_into(dst, src):
+    if torch.is_tensor(dst):
+        if dst.shape != src.shape or dst.dtype != src.dtype:
+            raise ValueError("a cached per-clip constant changed shape between clips of one graph key")
+        dst.copy_(src)
+    elif isinstance(dst, (tuple, list)):
+        if len(dst) != len(src):
+            raise ValueError("a cached per-clip constant changed arity between clips of one graph key")
+        for a, b in zip(dst, src):
+            _copy_into(a, b)
+    elif dst != src:
+        raise ValueError("a cached per-clip constant that is not a tensor changed between clips of one graph key")
 
 
 class _NoCache:

@@ -63,6 +63,7 @@ class HalloModule(nn.Module):
     """Base of the top-level native models: tracks device/dtype and lazy `prepare()`."""
 
     _prepared = False
+    prepare_epoch = 0        # bumped whenever prepare() rebuilds the weight images (captured graphs of older epochs are stale)
 
     @property
     def device(self):
@@ -94,6 +95,7 @@ class HalloModule(nn.Module):
         if hasattr(self, "_prepare"):
             self._prepare()
         self._prepared = True
+        self.prepare_epoch += 1
         return self
 
     # diffusers ModelMixin surface the reference's callers touch (scripts/inference.py:229-234)
@@ -202,11 +204,16 @@ class Attention(nn.Module):
         self.to_out = nn.ModuleList([Linear(inner, query_dim, bias=True), nn.Identity()])
 
     def _prepare(self):
+        # prepare() runs again after load_state_dict() / .to(): the fp8 images of the old weights must not survive it
+        for name in ("_w8", "_w8s", "_o8", "_o8s"):
+            self.__dict__.pop(name, None)
         self.w_kv = torch.cat([self.to_k.weight, self.to_v.weight], dim=0).contiguous()
         self.b_kv = (torch.cat([self.to_k.bias, self.to_v.bias]).contiguous() if self.to_k.bias is not None else None)
         if not self.is_cross:
             self.w_qkv = torch.cat([self.to_q.weight, self.w_kv], dim=0).contiguous()
             self.b_qkv = (torch.cat([self.to_q.bias, self.b_kv]).contiguous() if self.to_q.bias is not None else None)
+            if self.fp8:
+                self.set_fp8(True)              # re-quantise the rebuilt weights
 
     # -- fused projections -----------------------------------------------------------------
     def qkv(self, x):
@@ -242,7 +249,7 @@ class Attention(nn.Module):
     def set_fp8(self, enabled):
         """Quantise [to_q; to_k; to_v] and to_out.0 per output channel (once) and route qkv_ln() / out() through
         hallo_quant_rows_fp8 + hallo_gemm_fp8.  Needs prepared weights on the GPU; cross-attentions keep their bf16 path."""
-        if enabled and not self.is_cross and not hasattr(self, "_w8"):
+        if enabled and not self.is_cross and "_w8" not in self.__dict__:
             self._w8, self._w8s = ops.quant_rows_fp8(self.w_qkv)
             self._o8, self._o8s = ops.quant_rows_fp8(self.to_out[0].weight)
         self.fp8 = bool(enabled) and not self.is_cross
@@ -304,11 +311,18 @@ class FeedForward(nn.Module):
         g = self.net[0].proj
         self._ln_eps = norm.eps
         self._ln_w, self._ln_g, self._ln_b = ops.fold_layernorm(norm.weight, norm.bias, g.weight, g.bias)
+        # 320-wide blocks (64 x 64 latents): LayerNorm -> GEGLU -> net[2] -> + x as ONE kernel (hallo_ff320) on a packed weight image
+        self._ff_pack = None
+        if g.weight.shape[1] == ops.FF320_C and g.weight.shape[0] == 2 * ops.FF320_INNER and g.weight.is_cuda:
+            self._ff_pack = ops.ff320_pack(self._ln_w, self._ln_b, self.net[2].weight)
 
     def run_ln(self, x):
-        """x [N, L, C] UN-normalised -> ff(LayerNorm(x)) + x, the norm fused into the GEGLU GEMM."""
+        """x [N, L, C] UN-normalised -> ff(LayerNorm(x)) + x: one fused kernel for 320-wide blocks with enough rows, else the
+        norm fused into the GEGLU GEMM and the residual into net[2]'s."""
         N, L, Cd = x.shape
         x2 = x.view(N * L, Cd)
+        if self._ff_pack is not None and ops.ff320_enabled(N * L):
+            return ops.ff320(x2, self._ff_pack, self.net[2].bias, eps=self._ln_eps).view(N, L, Cd)
         h = ops.gemm(x2, self._ln_w, self._ln_b, geglu=True, ln_colsum=self._ln_g, ln_eps=self._ln_eps,
                      ln_stats=ops.ln_stats(x2, self._ln_w.shape[0] // 2, self._ln_eps, geglu=True))
         y = self.net[2].run(h, residual=x.view(N * L, Cd))

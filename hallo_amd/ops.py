@@ -407,6 +407,66 @@ def fold_layernorm(gamma, beta, w, bias=None):
     return wf, colsum, bf.to(w.dtype).contiguous()
 
 
+GELU_U_SCALE = 0.84932180028801904272        # csrc/common.h
+GELU_U_INV = 1.17741002251547469101
+FF320_C, FF320_INNER, FF320_STEP, FF320_IMAGE = 320, 1280, 16, 32768
+
+
+def ff320_pack(w1, b1, w2):
+    """Weight image of hallo_ff320 (layout: include/hallo_amd.h) from w1 [2560, 320] / b1 [2560] (GEGLU projection, LayerNorm
+    already folded in: fold_layernorm) and w2 [320, 1280] (net[2].weight).  Pure gathers on the device, once per module."""
+    Cd, I, CH = FF320_C, FF320_INNER, FF320_STEP
+    assert tuple(w1.shape) == (2 * I, Cd) and tuple(w2.shape) == (Cd, I) and b1.numel() == 2 * I and w1.dtype == w2.dtype
+    dev, ns = w1.device, I // CH
+    ar = lambda n: torch.arange(n, device=dev)
+    img = torch.zeros((ns, FF320_IMAGE), device=dev, dtype=torch.uint8)
+    # W1: [step][sub-tile t][row r][stored piece q][8]  <-  row src(step, r), k = 64 t + 8 (q ^ ((r >> 1) & 7)) + e
+    s_, t_, r_, q_, e_ = torch.meshgrid(ar(ns), ar(5), ar(32), ar(8), ar(8), indexing="ij")
+    src_row = torch.where(r_ < 16, CH * s_ + r_, I + CH * s_ + r_ - 16)
+    k = 64 * t_ + 8 * (q_ ^ ((r_ >> 1) & 7)) + e_
+    w1i = w1.contiguous()[src_row, k]                                            # [ns, 5, 32, 8, 8]
+    img[:, :20480] = w1i.reshape(ns, -1).view(torch.uint8)
+    # W2: [step][n][stored half p][e]  <-  column 16 s + (e & 3) + 8 (e >> 2) + 4 h, h = p ^ ((n >> 3) & 1)
+    s_, n_, p_, e_ = torch.meshgrid(ar(ns), ar(Cd), ar(2), ar(8), indexing="ij")
+    h_ = p_ ^ ((n_ >> 3) & 1)
+    col = CH * s_ + (e_ & 3) + 8 * (e_ >> 2) + 4 * h_
+    w2i = w2.contiguous()[n_, col]                                               # [ns, 320, 2, 8]
+    img[:, 20480:30720] = w2i.reshape(ns, -1).view(torch.uint8)
+    # b1: fp32 [step][h][value 8 | gate 8], gelu_u scales folded in
+    s_, h_, e_ = torch.meshgrid(ar(ns), ar(2), ar(8), indexing="ij")
+    col = CH * s_ + (e_ & 3) + 8 * (e_ >> 2) + 4 * h_
+    bf = b1.float()
+    bb = torch.cat([bf[col] * GELU_U_INV, bf[I + col] * GELU_U_SCALE], dim=2).contiguous()      # [ns, 2, 16]
+    img[:, 30720:30720 + 128] = bb.reshape(ns, -1).view(torch.uint8)
+    assert img.numel() == _l.load().hallo_ff320_pack_bytes()
+    return img
+
+
+FF320_MIN_ROWS = 24576      # 128 rows per workgroup, every workgroup streams all 2.6 MB of weights: below ~192 workgroups the two-GEMM path wins
+
+
+def ff320_enabled(rows):
+    """Routing rule of FeedForward.run_ln for 320-wide blocks: the fused kernel when enough rows fill the chip and
+    hallo_set_option("ff_fused", 0) has not switched it off."""
+    return rows >= FF320_MIN_ROWS and get_option("ff_fused") > 0
+
+
+def ff320(x2d, wpack, b2, *, residual=None, layernorm=True, eps=1e-5, out=None):
+    """out = residual + net2(GEGLU(net0(LayerNorm(x2d)))) for 320-wide rows in one kernel (hallo_ff320); residual defaults
+    to x2d, out may be x2d."""
+    _chk_dev(x2d, wpack, b2)
+    M, Cd = x2d.shape
+    assert Cd == FF320_C and x2d.stride(1) == 1 and wpack.dtype == torch.uint8 and wpack.is_contiguous() and b2.dtype == x2d.dtype
+    res = x2d if residual is None else residual
+    assert res.shape == x2d.shape and res.stride(1) == 1 and res.dtype == x2d.dtype
+    if out is None:
+        out = torch.empty((M, Cd), device=x2d.device, dtype=x2d.dtype)
+    assert out.shape == x2d.shape and out.stride(1) == 1 and out.dtype == x2d.dtype
+    _l.check(_l.load().hallo_ff320(_p(x2d), x2d.stride(0), _p(res), res.stride(0), _p(out), out.stride(0), _p(wpack), _p(b2), M,
+                                   1 if layernorm else 0, float(eps), dtype_code(x2d.dtype), _stream()), "hallo_ff320")
+    return out
+
+
 def row_stats(x2d, eps=1e-5):
     """(mean, rstd) per row of x2d [rows, C] as fp32 [rows, 2]: LayerNorm's statistics for hallo_gemm(ln_stats=...)."""
     _chk_dev(x2d)

@@ -279,6 +279,25 @@ typedef struct {
 int hallo_gemm_fp8(const hallo_gemm_fp8_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ABI v5: hallo_ff320 -- diffusers FeedForward(activation_fn="geglu") of a 320-wide transformer block with its LayerNorm and
+ * residual, `ff(norm3(x)) + x` (hallo/models/attention.py:601,905; hallo/models/motion_module.py:420), as ONE kernel:
+ *   y[m, :] = res[m, :] + b2 + W2 . GEGLU(W1' . LN(x[m, :]) + b1'),   GEGLU(v | g) = v * gelu_erf(g)
+ * with the LayerNorm affine folded by the caller (W1' = W1 * gamma, b1' = b1 + W1 . beta; layernorm = 0: x is used as is).
+ * The 1280-wide intermediate never reaches memory (csrc/gemm_ff.hip).  x / res / y: [M, 320] dtype with row strides ldx /
+ * ldr / ldy (elements; ldx, ldy % 8 == 0, ldr % 4 == 0; x, y 16-byte aligned); y may alias x and res.  b2: [320] dtype.
+ * wpack: hallo_ff320_pack_bytes() bytes, 80 images of 32 KB, image s = the weights of intermediate columns c0 = 16 s .. +15:
+ *   [0, 20480)      W1' rows: 5 sub-tiles t of [32 rows][64 k]: row r < 16 = value row c0 + r, r >= 16 = gate row 1280 + c0 +
+ *                   r - 16; the 16-byte piece pc (k = 64 t + 8 pc .. +7) of row r at byte 4096 t + 128 r + 16 (pc ^ ((r >> 1) & 7))
+ *   [20480, 30720)  W2: row n (0..319) at byte 32 n; its two 16-byte halves h hold the 8 k-slots e <-> column
+ *                   c0 + (e & 3) + 8 (e >> 2) + 4 h (the accumulator layout of the first MFMA), half h at 16 (h ^ ((n >> 3) & 1))
+ *   [30720, 30848)  fp32 [2 halves h][16]: b1'[c] * 1.1774100 for the 8 columns of half h, then b1'[1280 + c] * 0.8493218
+ *                   (the gelu_u scales, csrc/common.h); the rest of the image is padding
+ * (hallo_amd/ops.py ff320_pack builds it).  hallo_set_option("ff_fused", 0): host code keeps the two-hallo_gemm path. */
+int64_t hallo_ff320_pack_bytes(void);
+int hallo_ff320(const void* x, int64_t ldx, const void* res, int64_t ldr, void* y, int64_t ldy, const void* wpack,
+                const void* b2, int64_t M, int layernorm, float ln_eps, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * hallo_face_xattn: y = x + to_out(SDPA(to_q(LayerNorm(x)), K_face, V_face)) for a cross-attention over H*T = 32
  * (head, token) pairs -- norm2 + attn2 + residual of the spatial transformer block
  * (hallo/models/mutual_self_attention.py:286-303; 4 face tokens x 8 heads) in ONE pass over x.

@@ -228,6 +228,18 @@ def row_stats(x2d, eps=1e-5):
     return torch.stack([xf.mean(dim=1), torch.rsqrt(xf.var(dim=1, unbiased=False) + eps)], dim=1).contiguous()
 
 
+def ln_stats(x2d, n_out, eps=1e-5, *, geglu=False, bias2_rows_per_group=0, lead_cols=0):
+    """ops.ln_stats asks the LIBRARY whether its row-stationary kernel takes the problem; the emulation always hands the
+    statistics over (both routes compute the same LayerNorm), so the CPU host-logic suite never loads libhallo_amd.so."""
+    return row_stats(x2d, eps)
+
+
+def ff320_enabled(rows):
+    """The fused feed-forward kernel is a routing decision of the library build; the emulation keeps the two-GEMM form (the
+    same arithmetic)."""
+    return False
+
+
 def softmax_rows(x, out, scale):
     assert x.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous() and x.shape[-1] % 4 == 0
     out.copy_(torch.softmax(x * scale, dim=-1).to(out.dtype))
@@ -336,7 +348,7 @@ def lerp_rows(x, out_rows):
 
 
 EMULATED = ("dtype_code", "set_option", "get_option", "gemm", "gemm_batched", "conv3x3", "attention", "temporal_attention",
-            "groupnorm", "layernorm", "row_stats", "softmax_rows", "copy2d", "nchw_to_nhwc", "nhwc_to_nchw_f32",
+            "groupnorm", "layernorm", "row_stats", "ln_stats", "ff320_enabled", "softmax_rows", "copy2d", "nchw_to_nhwc", "nhwc_to_nchw_f32",
             "timestep_embedding", "cfg_ddim_step", "frames_to_uint8", "face_xattn", "w2v_conv0_gn_gelu", "lerp_rows")
 
 

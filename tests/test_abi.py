@@ -24,7 +24,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(hl.SYMBOLS), (declared ^ set(hl.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hallo_abi_version() == 4
+    assert lib.hallo_abi_version() == 5
 
 
 def test_struct_sizes_match_header(lib):
@@ -115,8 +115,14 @@ def test_every_entry_point_rejects_bad_arguments(lib):
     res['w2v_k']=lib.hallo_w2v_conv0_gn_gelu(p,16000,p,p,p,p,p,512,17,5,1e-5,0,N)
     res['lerp_null']=lib.hallo_lerp_rows(N,N,4,8,512,0,N)
     res['lerp_C']=lib.hallo_lerp_rows(p,p,4,8,20,0,N)
+    res['ff_null']=lib.hallo_ff320(N,320,N,320,N,320,N,N,128,1,1e-5,0,N)
+    res['ff_ld']=lib.hallo_ff320(p,324,p,320,p,320,p,p,128,1,1e-5,0,N)          # ldx not a multiple of 8
+    res['ff_dtype']=lib.hallo_ff320(p,320,p,320,p,320,p,p,128,1,1e-5,7,N)
+    res['ff_opt']=lib.hallo_set_option(b"ff_fused",3)
+    res['rsdbg_gated']=lib.hallo_set_option(b"gemm_rs_dbg",1)                    # timing ablations need a -DHALLO_ABLATIONS build
     res['opt_unknown']=lib.hallo_set_option(b"nope",1); res['get_unknown']=lib.hallo_get_option(b"nope")
     bad = {k: v for k, v in res.items() if v != -22}
     assert not bad, bad
     assert len(res) >= 36
     assert lib.hallo_groupnorm_chunks(4096) > 0
+    assert lib.hallo_ff320_pack_bytes() == 80 * 32768 and lib.hallo_get_option(b"gemm_rs_dbg") == 0 and lib.hallo_get_option(b"ff_fused") == 1

@@ -98,3 +98,34 @@ def test_reference_control_contract():
     assert den.reference_bank is None and ref.written_banks == []
     with pytest.raises(AssertionError):
         ReferenceAttentionControl(den, mode="bogus")
+
+
+def test_clip_cache_refreshes_constants_in_place():
+    """Graph mode (FaceAnimatePipeline(use_graph=True)): after begin_clip() the first get() of a key recomputes the value and
+    copies it INTO the tensors of the previous clip, so a captured hipGraph keeps reading valid addresses; shape changes
+    are refused."""
+    import pytest
+    import torch
+    from hallo_amd.models.attention import ClipCache
+    c = ClipCache()
+    owner = object()
+    made = []
+
+    def make(val):
+        def f():
+            made.append(val)
+            base = torch.full((2, 6), float(val))
+            return base[:, :3], base[:, 3:]          # views of one buffer, like the fused k|v projections
+        return f
+    k0, v0 = c.get(owner, "kv", make(1))
+    assert c.get(owner, "kv", make(2))[0] is k0 and made == [1]          # a hit: nothing recomputed
+    c.begin_clip()
+    k1, v1 = c.get(owner, "kv", make(3))
+    assert k1 is k0 and v1 is v0 and made == [1, 3]
+    assert float(k0[0, 0]) == 3.0 and float(v0[1, 2]) == 3.0             # refreshed inside the old storage
+    assert c.get(owner, "kv", make(4))[0] is k0 and made == [1, 3]       # fresh again until the next clip
+    c.begin_clip()
+    with pytest.raises(ValueError):
+        c.get(owner, "kv", lambda: (torch.zeros(2, 4), torch.zeros(2, 3)))
+    c.clear()
+    assert c.get(owner, "kv", make(5))[0] is not k0

@@ -168,6 +168,38 @@ def test_pipeline_end_to_end(nets, guidance, report):
     assert p >= 35.0
 
 
+@pytest.mark.parametrize("guidance", [3.5, 1.0])
+def test_pipeline_hipgraph_replay_is_byte_identical(nets, guidance, report):
+    """`use_graph=True`: the UNet evaluation is captured once and replayed for steps 1.. of every clip,
+    with the per-clip constants refreshed inside their old storage.  Same kernels, same order, deterministic kernels: the
+    frames of three consecutive clips with DIFFERENT inputs (the second and third run on the graph captured during the
+    first) must equal the eager pipeline's byte for byte."""
+    dtype, o, n = nets
+    from oracle import harness as Hn
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.scheduler import DDIMScheduler
+    S, Fr, steps = 128, 4, 4
+    mk = lambda: DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                               prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    kw = dict(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+              face_locator=n["face_locator"], image_proj=n["imageproj"])
+    eager = FaceAnimatePipeline(scheduler=mk(), **kw)
+    graphed = FaceAnimatePipeline(scheduler=mk(), use_graph=True, **kw)
+    rd = lambda t: t.to(dtype).float()
+    for clip in range(3):
+        d = Hn.clip_inputs(S, Fr, seed=1234 + clip)
+        lat = rd(torch.randn(d["latents"].shape, generator=torch.Generator().manual_seed(42 + clip)))
+        args = (rd(d["ref_image"]), rd(d["face_emb"]), rd(d["audio"]), d["face_mask"], [rd(m) for m in d["full"]],
+                [rd(m) for m in d["face"]], [rd(m) for m in d["lip"]], S, S, Fr, steps, guidance)
+        ms = [1.0, 0.8, 1.2]
+        a = eager(*args, motion_scale=ms, latents=lat).videos
+        b = graphed(*args, motion_scale=ms, latents=lat).videos
+        assert torch.equal(a, b), (clip, (a - b).abs().max().item())
+    (sg,) = graphed._graphs.values()
+    assert sg.graph is not None and sg.replays == 3 * (steps - 1)
+    report.append({"test": f"pipeline_hipgraph_byte_identical[gs={guidance}]", "dtype": str(dtype), "clips": 3, "replays": sg.replays})
+
+
 # ------------------------------------------------------------------------------------------------
 # SURVEY 8f rows 1 + 3: the sliding-window driver (motion-frame carry on the device, shared generator stream)
 # and the uint8 output conversion

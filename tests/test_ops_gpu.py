@@ -702,3 +702,47 @@ def test_attn_processor_plugin_seam(dtype, hd, Lq, ctx_len, report):
     _check(f"attn_processor_seam[{hd},{Lq},{ctx_len}]", out, ref, dtype, report, scale=2.0)     # + the torch projections' rounding
     with pytest.raises(NotImplementedError):
         mod(x, encoder_hidden_states=ctx, attention_mask=torch.zeros((B, 1, Lq), device=_dev()))
+
+
+# --------------------------------------------------------------------------------------------
+# hallo_ff320 (csrc/gemm_ff.hip): LayerNorm -> GEGLU -> net[2] -> + residual of a 320-wide block as one kernel
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,ln", [(389, True), (24576, True), (65536, True), (73728 - 40, False)])
+def test_ff320_fused_feed_forward(dtype, M, ln, report):
+    """diffusers FeedForward(geglu) with the block's LayerNorm and residual (hallo/models/attention.py:601,905,
+    motion_module.py:420) through hallo_ff320 vs the fp32 expression; ragged M (rows past the last 128-row workgroup), a
+    residual that is not x, in-place output, and agreement with the two-hallo_gemm path it replaces."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(320 + M)
+    Cd, I = 320, 1280
+    x = _rand((M, Cd), dtype, g) * 1.2 - 0.3
+    gamma = (1.0 + 0.1 * torch.randn((Cd,), generator=g)).to(dtype).to(_dev())
+    beta = _rand((Cd,), dtype, g, 0.1)
+    w1 = _rand((2 * I, Cd), dtype, g, Cd ** -0.5)
+    b1 = _rand((2 * I,), dtype, g, 0.1)
+    w2 = _rand((Cd, I), dtype, g, I ** -0.5)
+    b2 = _rand((Cd,), dtype, g, 0.1)
+    res = _rand((M, Cd), dtype, g)
+    if ln:
+        wf, cs, bf = ops.fold_layernorm(gamma, beta, w1, b1)
+        nh = torch.nn.functional.layer_norm(x.float(), (Cd,), gamma.float(), beta.float(), 1e-5)
+    else:
+        wf, bf, nh = w1, b1, x.float()
+    pack = ops.ff320_pack(wf, bf, w2)
+    ref_h = ops_ref.geglu(nh, w1, b1)
+    ref = ref_h @ w2.float().t() + b2.float()
+    out = ops.ff320(x, pack, b2, residual=res, layernorm=ln)
+    _check(f"ff320[{M},ln={ln}]", out, ref + res.float(), dtype, report)
+    # the intermediate of the two-GEMM path is rounded to the storage type like the fused kernel's P fragments: closer than to fp32
+    if ln:
+        h = ops.gemm(x, wf, bf, geglu=True, ln_colsum=cs, ln_eps=1e-5, ln_stats=ops.ln_stats(x, I, 1e-5, geglu=True))
+    else:
+        h = ops.gemm(x, wf, bf, geglu=True)
+    two = ops.gemm(h, w2, b2, residual=res)
+    _check(f"ff320_vs_two_gemm[{M},ln={ln}]", out, two, dtype, report)
+    xc = x.clone()
+    ops.ff320(xc, pack, b2, layernorm=ln, out=xc)                              # in place, residual = x
+    _check(f"ff320_inplace[{M},ln={ln}]", xc, ref + x.float(), dtype, report)
+    again = ops.ff320(x, pack, b2, residual=res, layernorm=ln)
+    assert torch.equal(out, again)                                           # bit-reproducible

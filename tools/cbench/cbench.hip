@@ -10,6 +10,7 @@
 //   tools/cbench/cbench attn-time [variants]     L0 spatial attention timings per variant (e.g. 0,1,2)
 //   tools/cbench/cbench gemm M N K [geglu] [ln] [res] [rs=0|1] [variant=v]
 //   tools/cbench/cbench gemm-suite               the step's dominant GEMM shapes
+//   tools/cbench/cbench ff M [f16] [noln]        fused feed-forward (hallo_ff320) vs fp32 reference and vs the two-GEMM path
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
@@ -394,6 +395,124 @@ static GemmOpts parse_gemm(int argc, char** argv) {
   return g;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fused feed-forward (hallo_ff320): y = x + net2(GEGLU(net0(LN(x)))) for C = 320, against a two-stage fp32 reference and the
+// two-GEMM path it replaces
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void ff2_ref(const float* H, const uint16_t* W2, const uint16_t* b2, const uint16_t* X, float* Y, int rows, int row0, int C, int I, int dt) {
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)rows * C) return;
+  int n = i % C; int r = i / C;
+  float acc = 0.0f;
+  for (int c = 0; c < I; ++c) acc += H[(long)r * I + c] * to_f(W2[(long)n * I + c], dt);
+  Y[i] = acc + to_f(b2[n], dt) + to_f(X[(long)(row0 + r) * C + n], dt);
+}
+
+// host packer: mirrors hallo_amd/ops.py ff320_pack (include/hallo_amd.h documents the image)
+static uint16_t host_from_f(float f, int dt) {
+  if (dt == 1) { uint32_t u; memcpy(&u, &f, 4); uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u); return (uint16_t)(r >> 16); }
+  _Float16 h = (_Float16)f; uint16_t v; memcpy(&v, &h, 2); return v;
+}
+static std::vector<uint8_t> ff_pack(const std::vector<uint16_t>& w1f, const std::vector<uint16_t>& b1f, const std::vector<uint16_t>& w2, int dt) {
+  const int C = 320, I = 1280, NS = 80, CH = 32768;
+  const float INV = 1.17741002251547469101f, SC = 0.84932180028801904272f;
+  std::vector<uint8_t> img((size_t)NS * CH, 0);
+  for (int s = 0; s < NS; ++s) {
+    uint8_t* base = img.data() + (size_t)s * CH;
+    const int c0 = 16 * s;
+    for (int t = 0; t < 5; ++t) for (int r = 0; r < 32; ++r) for (int pc = 0; pc < 8; ++pc) {
+      const int src_row = r < 16 ? c0 + r : I + c0 + (r - 16);
+      const uint16_t* src = &w1f[(size_t)src_row * C + t * 64 + pc * 8];
+      memcpy(base + t * 4096 + r * 128 + ((pc ^ ((r >> 1) & 7)) * 16), src, 16);
+    }
+    for (int n = 0; n < C; ++n) for (int h = 0; h < 2; ++h) for (int e = 0; e < 8; ++e) {
+      const int c = c0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      memcpy(base + 20480 + n * 32 + ((h ^ ((n >> 3) & 1)) * 16) + e * 2, &w2[(size_t)n * I + c], 2);
+    }
+    float* bp = reinterpret_cast<float*>(base + 30720);
+    for (int h = 0; h < 2; ++h) for (int e = 0; e < 8; ++e) {
+      const int c = c0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      bp[h * 16 + e] = host_to_f(b1f[c], dt) * INV;
+      bp[h * 16 + 8 + e] = host_to_f(b1f[I + c], dt) * SC;
+    }
+  }
+  return img;
+}
+
+static int cmd_ff(int argc, char** argv) {
+  const int C = 320, I = 1280;
+  int M = argc > 0 ? atoi(argv[0]) : 65536, dt = DT_BF16; bool ln = true;
+  for (int i = 1; i < argc; ++i) { std::string a = argv[i]; if (a == "f16") dt = DT_F16; else if (a == "noln") ln = false; }
+  Timer tm;
+  uint16_t* X = dalloc<uint16_t>((long)M * C); uint16_t* Y = dalloc<uint16_t>((long)M * C); uint16_t* Y2 = dalloc<uint16_t>((long)M * C);
+  uint16_t* Hb = dalloc<uint16_t>((long)M * I);
+  uint16_t* W1 = dalloc<uint16_t>((long)2 * I * C); uint16_t* W1f = dalloc<uint16_t>((long)2 * I * C); uint16_t* b1 = dalloc<uint16_t>(2 * I);
+  uint16_t* b1f = dalloc<uint16_t>(2 * I); float* cs = dalloc<float>(2 * I);
+  uint16_t* gamma = dalloc<uint16_t>(C); uint16_t* beta = dalloc<uint16_t>(C); uint16_t* W2 = dalloc<uint16_t>((long)C * I); uint16_t* b2 = dalloc<uint16_t>(C);
+  fill(X, (long)M * C, 1, 1.2f, -0.3f, dt); fill(W1, (long)2 * I * C, 2, 1.0f / sqrtf((float)C), 0.0f, dt); fill(b1, 2 * I, 3, 0.1f, 0.0f, dt);
+  fill(gamma, C, 4, 0.1f, 1.0f, dt); fill(beta, C, 5, 0.1f, 0.0f, dt); fill(W2, (long)C * I, 6, 1.0f / sqrtf((float)I), 0.0f, dt); fill(b2, C, 7, 0.1f, 0.0f, dt);
+  if (ln) hipLaunchKernelGGL(fold_ln, dim3((2 * I + 63) / 64), dim3(64), 0, 0, W1, b1, gamma, beta, W1f, b1f, cs, 2 * I, C, dt);
+  else { CK(hipMemcpy(W1f, W1, (size_t)2 * I * C * 2, hipMemcpyDeviceToDevice)); CK(hipMemcpy(b1f, b1, 2 * I * 2, hipMemcpyDeviceToDevice)); }
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> hw1((size_t)2 * I * C), hb1(2 * I), hw2((size_t)C * I);
+  CK(hipMemcpy(hw1.data(), W1f, hw1.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb1.data(), b1f, hb1.size() * 2, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hw2.data(), W2, hw2.size() * 2, hipMemcpyDeviceToHost));
+  std::vector<uint8_t> img = ff_pack(hw1, hb1, hw2, dt);
+  if ((int64_t)img.size() != hallo_ff320_pack_bytes()) { fprintf(stderr, "pack size mismatch\n"); return 4; }
+  uint8_t* dimg = dalloc<uint8_t>(img.size()); CK(hipMemcpy(dimg, img.data(), img.size(), hipMemcpyHostToDevice));
+  static void* ws = nullptr; const long ws_bytes = 256L << 20; if (!ws) CK(hipMalloc(&ws, ws_bytes));
+  // the two-GEMM path
+  hallo_gemm_desc d1; memset(&d1, 0, sizeof d1);
+  d1.A = X; d1.B = W1f; d1.C = Hb; d1.M = M; d1.N = I; d1.K = C; d1.lda = C; d1.ldb = C; d1.ldc = I; d1.batch = 1; d1.bias = b1f; d1.alpha = 1.0f;
+  d1.geglu = 1; d1.dtype = dt; d1.lead_alpha = 1.0f; d1.workspace = ws; d1.workspace_bytes = ws_bytes;
+  float* stats = dalloc<float>((long)M * 2);
+  const bool fused_stats = ln && hallo_gemm_fuses_row_stats(M, I, C, 1, 0, 0);
+  if (ln) { d1.ln_colsum = cs; d1.ln_eps = 1e-5f; if (!fused_stats) d1.ln_stats = stats; }
+  hallo_gemm_desc d2; memset(&d2, 0, sizeof d2);
+  d2.A = Hb; d2.B = W2; d2.C = Y2; d2.M = M; d2.N = C; d2.K = I; d2.lda = I; d2.ldb = I; d2.ldc = C; d2.batch = 1; d2.bias = b2; d2.alpha = 1.0f;
+  d2.residual = X; d2.ldr = C; d2.dtype = dt; d2.lead_alpha = 1.0f; d2.workspace = ws; d2.workspace_bytes = ws_bytes;
+  auto pair = [&] { if (ln && !fused_stats) HK(hallo_row_stats(X, stats, M, C, 1e-5f, dt, nullptr)); HK(hallo_gemm(&d1, nullptr)); HK(hallo_gemm(&d2, nullptr)); };
+  auto fusedk = [&] { HK(hallo_ff320(X, C, X, C, Y, C, dimg, b2, M, ln ? 1 : 0, 1e-5f, dt, nullptr)); };
+  pair(); CK(hipDeviceSynchronize());
+  // fp32 reference on the first and last rows
+  const int rows = std::min(M, 256);
+  float* Href = dalloc<float>((long)rows * I); float* Yref = dalloc<float>((long)rows * C);
+  std::vector<float> href((size_t)rows * C); std::vector<uint16_t> out((size_t)M * C), out2((size_t)M * C), outp((size_t)M * C);
+  CK(hipMemcpy(outp.data(), Y2, outp.size() * 2, hipMemcpyDeviceToHost));
+  for (int variant = 1; variant <= 2; ++variant) {
+    HK(hallo_set_option("ff_fused", variant));
+    CK(hipMemset(Y, 0xFF, (size_t)M * C * 2));
+    fusedk(); CK(hipDeviceSynchronize());
+    CK(hipMemcpy(out.data(), Y, out.size() * 2, hipMemcpyDeviceToHost));
+    double en = 0, rn = 0, ep = 0; long nan = 0; int nondet = 0;
+    for (int part = 0; part < 2; ++part) {
+      const int row0 = part ? M - rows : 0;
+      hipLaunchKernelGGL(gemm_ref, dim3(((long)rows * I + 255) / 256), dim3(256), 0, 0, X, W1, b1, gamma, beta, (const uint16_t*)nullptr, Href, M, I, C, 1, (int)ln, dt, rows, row0);
+      hipLaunchKernelGGL(ff2_ref, dim3(((long)rows * C + 255) / 256), dim3(256), 0, 0, Href, W2, b2, X, Yref, rows, row0, C, I, dt);
+      CK(hipMemcpy(href.data(), Yref, href.size() * 4, hipMemcpyDeviceToHost));
+      for (long i = 0; i < (long)rows * C; ++i) {
+        const float x = host_to_f(out[(size_t)row0 * C + i], dt), xp = host_to_f(outp[(size_t)row0 * C + i], dt);
+        double e = x - href[i]; en += e * e; rn += (double)href[i] * href[i]; e = xp - href[i]; ep += e * e;
+      }
+    }
+    double dn = 0, pn = 0;
+    for (size_t i = 0; i < out.size(); ++i) { const float x = host_to_f(out[i], dt), xp = host_to_f(outp[i], dt); if (x != x) ++nan; double e = x - xp; dn += e * e; pn += (double)xp * xp; }
+    for (int r = 0; r < 3; ++r) { fusedk(); CK(hipDeviceSynchronize()); CK(hipMemcpy(out2.data(), Y, out2.size() * 2, hipMemcpyDeviceToHost)); if (memcmp(out.data(), out2.data(), out.size() * 2)) ++nondet; }
+    tm.run(fusedk, 3);
+    std::vector<float> t; for (int r = 0; r < g_rounds; ++r) t.push_back(tm.run(fusedk, g_iters));
+    const float us = median(t);
+    const double flop = 2.0 * M * (double)(2 * I) * C + 2.0 * M * (double)I * C;
+    printf("ff M=%d dt=%s ln=%d ff_fused=%d: %.1f us  %.1f TFLOP/s  rel_l2(vs fp32, first+last %d rows)=%.2e  [two-GEMM path: %.2e]  rel_l2(vs two-GEMM, all rows)=%.2e nan=%ld nondet=%d\n",
+           M, dt ? "bf16" : "f16", (int)ln, variant, us, flop / us / 1e6, rows, sqrt(en / rn), sqrt(ep / rn), sqrt(dn / pn), nan, nondet);
+    fflush(stdout);
+  }
+  HK(hallo_set_option("ff_fused", 1));
+  tm.run(pair, 3);
+  std::vector<float> t; for (int r = 0; r < g_rounds; ++r) t.push_back(tm.run(pair, g_iters));
+  printf("ff M=%d dt=%s ln=%d two-GEMM path (kernel %d fused_stats=%d): %.1f us\n", M, dt ? "bf16" : "f16", (int)ln, hallo_get_option("last_gemm_kernel"), (int)fused_stats, median(t));
+  return 0;
+}
+
 static int cmd_gemm_suite(int argc, char** argv) {
   Timer tm;
   struct S { int M, N, K; bool geglu, ln, res; };
@@ -424,6 +543,7 @@ int main(int argc, char** argv) {
   if (cmd == "attn-time") return cmd_attn_time(argc - 2, argv + 2);
   if (cmd == "gemm" && argc >= 5) { Timer tm; run_gemm_case(parse_gemm(argc - 2, argv + 2), tm); return 0; }
   if (cmd == "gemm-suite") return cmd_gemm_suite(argc - 2, argv + 2);
+  if (cmd == "ff") return cmd_ff(argc - 2, argv + 2);
   fprintf(stderr, "unknown command\n");
   return 64;
 }
