@@ -574,20 +574,23 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const T* __rest
     qf[ks] = (d < HD) ? ld8<T>(qrow + d) : zero8<T>();
     kf[ks] = (d < HD) ? ld8<T>(krow + d) : zero8<T>();
   }
-  // V^T gathers issued early: slot (ks2, hi, e) <-> frame j = 8*(2*ks2 + (e >> 2)) + 4*hi + (e & 3)
-  typedef __attribute__((ext_vector_type(2))) T V2t;
-  V8 vf[NDB][2];
+  // V^T (A operand of O^T = V^T . P^T): k-slot (ks2, hi, e) <-> frame j = 8*(2*ks2 + (e >> 2)) + 4*hi + (e & 3).
+  // Round 3: the V rows are read like Q and K -- 16-byte loads, lane = frame -- parked row-major in a wave-private LDS tile
+  // [32 frames][HDP] and read back TRANSPOSED with ds_read_b64_tr_b16 (each 16-lane group fetches a [4 frames][16 d] block, lane
+  // i of the group receives column i).  The first form gathered V^T with 32 two-byte global loads per lane, which held the
+  // kernel at 3.2 TB/s (40 % of the HBM peak; profiles/r2_bench.json attention_families).
+  constexpr int VP = HDP * 2;                         // row pitch in bytes: 96 / 160 / 320 -> the 4 rows of a transposing read fall on disjoint banks
+  __shared__ __attribute__((aligned(16))) unsigned char vt_smem[4 * 32 * VP];
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  lds_u8* const vt = (lds_u8*)vt_smem + wave * (32 * VP);
+  {
+    const T* vrow = qrow + 2 * C;
 #pragma unroll
-  for (int db = 0; db < NDB; ++db) {
-    const int d = db * 32 + l31;
-    const T* vcol = base + 2 * C + min(d, HD - 1);
-#pragma unroll
-    for (int ks2 = 0; ks2 < 2; ++ks2)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int j = 8 * (2 * ks2 + (e >> 2)) + 4 * hi + (e & 3);
-        vf[db][ks2][e] = vcol[min(j, F - 1) * fstride];
-      }
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int d = ks * 16 + hi * 8;
+      const V8 v8 = (d < HD) ? ld8<T>(vrow + d) : zero8<T>();
+      *(__attribute__((address_space(3))) V8*)(vt + l31 * VP + d * 2) = v8;
+    }
   }
   f32x16 s;
 #pragma unroll
@@ -619,10 +622,24 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const T* __rest
   // ---- O^T = V^T . P^T, normalise, store rows i < F (lane = query frame, 8-byte stores) ----
   const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   T* orow = out + ((b * F + fr) * (long)HW + pix) * C + (long)h * HD;
+  // the tile is private to the wave: LDS operations of one wave complete in order, no barrier
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int gi = lane & 15, gdh = (lane >> 4) & 1;
+  const lds_u8* const vb = vt + (4 * hi + (gi >> 2)) * VP + (gi & 3) * 8;
+  auto vfrag = [&](int db, int ks2) {
+    // columns d = db*32 + gdh*16 + i of frames 16*ks2 + 4*hi + 0..3 (slots 0..3) and + 8 (slots 4..7).  Groups whose columns lie
+    // past the padded head dim re-read the last 16 columns: those output rows (d >= HD) are never stored
+    const int cb = min(db * 32 + gdh * 16, HDP - 16) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + (16 * ks2) * VP + cb));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + (16 * ks2 + 8) * VP + cb));
+    const s16x8 v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(V8, v);
+  };
 #pragma unroll
   for (int db = 0; db < NDB; ++db) {
-    f32x16 o = Vec<T>::mfma32(vf[db][0], pf[0], zero16);
-    o = Vec<T>::mfma32(vf[db][1], pf[1], o);
+    f32x16 o = Vec<T>::mfma32(vfrag(db, 0), pf[0], zero16);
+    o = Vec<T>::mfma32(vfrag(db, 1), pf[1], o);
     if (l31 < F) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {

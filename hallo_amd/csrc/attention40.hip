@@ -150,46 +150,43 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
 #define A40_DMA(rs, dst, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + (dst)), 16, (int)(voff), (int)(soff), 0, 0)
 
-  auto dma_k = [&](int it) {
-    const bool s2 = it >= nt1;
-    if (it == nt1) set_segment_k(p.k2_rs);     // wave-uniform, once per kernel
-    const long krs = s2 ? p.k2_rs : p.k1_rs;
-    const int L = s2 ? p.Lkv2 : p.Lkv1;
-    const int kv0 = (s2 ? it - nt1 : it) * KVB;
-    const int so = (int)(kv0 * krs * 2);
-    const int st = (it & 1) * A40_K_TILE;
+  // Stream cursors (round 3).  The K stream runs three tiles ahead of the tile being consumed, the V stream one: each keeps
+  // its OWN position -- descriptor of the current segment, scalar byte offset of the next tile, rows left in the segment --
+  // and moves to the second segment in a rarely taken wave-uniform branch.  The per-tile issue is then: [ragged check],
+  // DMA, offset += step, tile counter; the round-2 form re-derived segment, descriptor and offset from the tile index for
+  // every issue (selects and branches over two descriptors: ~50 scalar instructions and 8 branches per tile in the ISA).
+  __amdgpu_buffer_rsrc_t cK_rs = rsK1, cV_rs = rsV1;
+  int cK_so = 0, cK_step = (int)(KVB * p.k1_rs * 2), cK_left = p.Lkv1, cK_tiles = nt1;
+  int cV_so = 0, cV_step = (int)(KVB * p.v1_rs * 2), cV_left = p.Lkv1, cV_tiles = nt1;
+  auto dma_k = [&](auto stg_c) {
+    constexpr int st = decltype(stg_c)::value * A40_K_TILE;
     unsigned o0 = offK0, o1 = offK1;
-    if (__builtin_expect(kv0 + KVB > L, 0)) {
-      o0 = (kv0 + krow0 < L) ? o0 : OOB;
-      o1 = (kv0 + krow1 < L) ? o1 : OOB;
+    if (__builtin_expect(cK_left < KVB, 0)) {
+      o0 = (krow0 < cK_left) ? o0 : OOB;
+      o1 = (krow1 < cK_left) ? o1 : OOB;
     }
-    if (s2) {
-      A40_DMA(rsK2, k_dst0 + st, o0, so);
-      if (wave_u == 0) A40_DMA(rsK2, k_dst1 + st, o1, so);
-    } else {
-      A40_DMA(rsK1, k_dst0 + st, o0, so);
-      if (wave_u == 0) A40_DMA(rsK1, k_dst1 + st, o1, so);
+    A40_DMA(cK_rs, k_dst0 + st, o0, cK_so);
+    if (wave_u == 0) A40_DMA(cK_rs, k_dst1 + st, o1, cK_so);
+    cK_so += cK_step; cK_left -= KVB;
+    if (__builtin_expect(--cK_tiles == 0, 0)) {        // the next tile opens the second segment (if any)
+      cK_rs = rsK2; cK_so = 0; cK_step = (int)(KVB * p.k2_rs * 2); cK_left = p.Lkv2; cK_tiles = nt2;
+      set_segment_k(p.k2_rs);
     }
   };
-  auto dma_v = [&](int it) {
-    const bool s2 = it >= nt1;
-    if (it == nt1) set_segment_v(p.v2_rs);
-    const long vrs = s2 ? p.v2_rs : p.v1_rs;
-    const int L = s2 ? p.Lkv2 : p.Lkv1;
-    const int kv0 = (s2 ? it - nt1 : it) * KVB;
-    const int so = (int)(kv0 * vrs * 2);
-    const int st0 = (it & 1) * v_stage0, st1 = (it & 1) * A40_VA_TILE;
+  auto dma_v = [&](auto stg_c) {
+    constexpr int stg = decltype(stg_c)::value;
+    const int st0 = stg * v_stage0, st1 = stg * A40_VA_TILE;
     unsigned o0 = offV0, o1 = offV1;
-    if (__builtin_expect(kv0 + KVB > L, 0)) {
-      o0 = (kv0 + vrow0 < L) ? o0 : OOB;
-      o1 = (kv0 + vrow1 < L) ? o1 : OOB;
+    if (__builtin_expect(cV_left < KVB, 0)) {
+      o0 = (vrow0 < cV_left) ? o0 : OOB;
+      o1 = (vrow1 < cV_left) ? o1 : OOB;
     }
-    if (s2) {
-      A40_DMA(rsV2, v_dst0 + st0, o0, so);
-      if (wave_u == 1) A40_DMA(rsV2, v_dst1 + st1, o1, so);
-    } else {
-      A40_DMA(rsV1, v_dst0 + st0, o0, so);
-      if (wave_u == 1) A40_DMA(rsV1, v_dst1 + st1, o1, so);
+    A40_DMA(cV_rs, v_dst0 + st0, o0, cV_so);
+    if (wave_u == 1) A40_DMA(cV_rs, v_dst1 + st1, o1, cV_so);
+    cV_so += cV_step; cV_left -= KVB;
+    if (__builtin_expect(--cV_tiles == 0, 0)) {
+      cV_rs = rsV2; cV_so = 0; cV_step = (int)(KVB * p.v2_rs * 2); cV_left = p.Lkv2; cV_tiles = nt2;
+      set_segment_v(p.v2_rs);
     }
   };
 #undef A40_DMA
@@ -242,33 +239,35 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   //   C  remaining exponentials | O^T += V^T . P^T of tile it (V stage it&1)
   //   D  DMA V(it+1) -> V stage (it+1)&1 (last read in C of it-1) and K(it+3) -> K stage (it+1)&1 (last read in A of it)
   f32x16 s_a[NT], s_b[NT];
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  int cons_left = p.Lkv1, cons_tiles = nt1;      // the tile being consumed: rows left / tiles left in its segment
   if (nt > 0) {
-    dma_k(0);
-    dma_v(0);
-    if (nt > 1) dma_k(1);
+    dma_k(S0{});
+    dma_v(S0{});
+    if (nt > 1) dma_k(S1{});
   }
   __syncthreads();                      // vmcnt(0) + barrier: constants and the first tiles are visible
   if (nt > 0) qk(std::integral_constant<int, 0>{}, s_a);
   __syncthreads();                      // every wave has read K(0) before K(2) lands in its stage
-  if (nt > 2) dma_k(2);
+  if (nt > 2) dma_k(S0{});
 
   auto tile_step = [&](auto more_c, auto par_c, int it, f32x16* s_cur, f32x16* s_nxt) {
     constexpr bool MORE = decltype(more_c)::value;      // a tile it+1 exists
     constexpr int PAR = decltype(par_c)::value;         // it & 1
 
-    const bool s2 = it >= nt1;
-    const int L = s2 ? p.Lkv2 : p.Lkv1;
-    const int kv0 = (s2 ? it - nt1 : it) * KVB;
-    if (__builtin_expect(kv0 + KVB > L, 0)) {
+    if (__builtin_expect(cons_left < KVB, 0)) {
       asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int kv = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          s_cur[t][r] = (kv < L) ? s_cur[t][r] : -3.0e38f;
+          const int kv = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          s_cur[t][r] = (kv < cons_left) ? s_cur[t][r] : -3.0e38f;
         }
     }
+    cons_left -= KVB;
+    if (__builtin_expect(--cons_tiles == 0, 0)) { cons_left = p.Lkv2; cons_tiles = nt2; }
     float mx = -3.0e38f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -337,8 +336,8 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
     }
     if (PRIO) __builtin_amdgcn_s_setprio(0);
     // ---- D ----
-    if (MORE) dma_v(it + 1);
-    if (it + 3 < nt) dma_k(it + 3);
+    if (MORE) dma_v(std::integral_constant<int, 1 - PAR>{});
+    if (it + 3 < nt) dma_k(std::integral_constant<int, 1 - PAR>{});
   };
   {
     using TT = std::true_type;

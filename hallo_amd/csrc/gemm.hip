@@ -1046,7 +1046,14 @@ extern "C" int hallo_set_option(const char* name, int value) {
   if (!strcmp(name, "conv_fast")) { if (value < 0 || value > 1) return -22; g_conv_fast = value; return 0; }
   if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }
   if (!strcmp(name, "gemm_rs")) { if (value < 0 || value > 2) return -22; g_gemm_rs = value; return 0; }
-  if (!strcmp(name, "ff_fused")) { if (value < 0 || value > 2) return -22; set_ff_fused_variant(value); return 0; }
+  if (!strcmp(name, "ff_fused")) {          // 0 / 1; 2.. = A/B and timing-ablation forms of a -DHALLO_ABLATIONS build
+#ifdef HALLO_ABLATIONS
+    if (value < 0 || value > 9) return -22;
+#else
+    if (value < 0 || value > 1) return -22;
+#endif
+    set_ff_fused_variant(value); return 0;
+  }
   if (!strcmp(name, "gemm_rs_dbg")) {
     // timing ablations of the row-stationary kernels (no stores / no epilogue: WRONG results): only a library built with
     // -DHALLO_ABLATIONS (HALLO_ABLATIONS=1 python -m hallo_amd.build, what tools/cbench uses) accepts a non-zero value

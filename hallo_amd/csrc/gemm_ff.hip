@@ -22,6 +22,17 @@
 //     swizzles applied at packing time), streamed through a 4-slot LDS ring by `buffer_load ... lds`: 8 instructions per
 //     wave per step, two steps in flight behind a counted vmcnt, one barrier per step.  Every workgroup streams all 2.6 MB
 //     (L2-resident) past its rows.
+//
+// Measured (round 3, tools/cbench ff 65536, bf16; s_memtime stamps of one wave, VAR & 64): 219 us against 193 us for the two
+// kernels it replaces, although it moves a third of their HBM bytes.  Per pair of chunks a wave spends ~370 cycles waiting for
+// the DMA, ~110 in the barrier, ~2150 in the first GEMM (40 MFMAs = 1280 cycles of matrix pipe) and ~1450 in the second (20
+// MFMAs = 640), plus 11 k + 21 k cycles of prologue / epilogue: 4100 cycles per 60 MFMAs.  With ONE wave per SIMD every
+// instruction of the step competes for that wave's issue slots: 270 VALU instructions (16 erf-GELUs with an rcp and an exp2
+// each, 32 accumulator moves) per 40 MFMAs are 6.7 per MFMA gap where ~5 fit (MI355X_MICROARCH.md), the 64 transcendentals
+// cost four slots each, and 16 LDS-DMA issues take ~50 cycles apiece.  Removing parts (ablations 4 / 8 / 32) saves exactly
+// their own issue time: nothing overlaps.  The two-kernel path runs two waves per SIMD and overlaps them.  What would fix it
+// is a producer / consumer split (one wave per SIMD multiplying, its partner doing GEGLU + second GEMM from an LDS hand-off),
+// which needs the consumer inside 256 registers with a 160-register accumulator; not built.  The kernel stays as an option.
 #include "gemm_args.h"
 #include <type_traits>
 
@@ -33,10 +44,16 @@ constexpr int FF_NSTEP = FF_INNER / FF_CH;                    // 80
 constexpr int FF_W1_BYTES = 32 * FF_C * 2;                    // 20480: 5 sub-tiles [32 rows][64 k], 128-byte rows, XOR-swizzled
 constexpr int FF_W2_BYTES = FF_C * FF_CH * 2;                 // 10240: [320 n][16 k-slots], 32-byte rows, halves swizzled
 constexpr int FF_B1_OFF = FF_W1_BYTES + FF_W2_BYTES;          // 30720: fp32 [2 halves][16] scaled value / gate biases
-constexpr int FF_CHUNK = 32768;
-constexpr int FF_RING = 4;
-constexpr int FF_LDS = FF_RING * FF_CHUNK;                    // 131072
-constexpr int FF_DMA = FF_CHUNK / 1024 / 4;                   // 8 LDS-DMA instructions per wave per step
+constexpr int FF_CHUNK = 32768;                               // bytes of one chunk image in the packed weight buffer
+constexpr int FF_W2_SLOT = FF_CHUNK - FF_W1_BYTES;            // 12288: W2 + b1 + padding of a chunk
+// LDS: the W1 parts of 2 chunk pairs (the pair being multiplied, the pair in flight) and the W2 / b1 parts of 3 pairs (the
+// second GEMM of pair t-1 runs at the END of step t, while pair t+1 is already landing)
+constexpr int FF_W1_RING = 2, FF_W2_RING = 3;
+constexpr int FF_OFF_W2 = FF_W1_RING * 2 * FF_W1_BYTES;       // 81920
+constexpr int FF_LDS = FF_OFF_W2 + FF_W2_RING * 2 * FF_W2_SLOT;   // 155648
+static_assert(FF_LDS <= 160 * 1024, "LDS");
+constexpr int FF_DMA = FF_CHUNK / 1024 / 4;                   // 8 LDS-DMA instructions per wave per chunk: 5 of W1, 3 of W2 / b1
+constexpr int FF_DMA_W1 = FF_W1_BYTES / 1024 / 4;             // 5
 }  // namespace
 
 struct FfArgs {
@@ -47,6 +64,7 @@ struct FfArgs {
   const void* b2;                   // [320] storage type
   int M;
   float ln_eps;
+  long long* dbg;                   // timing instrumentation (VAR & 64, -DHALLO_ABLATIONS builds): s_memtime stamps of wave 0 of workgroup 0
 };
 
 template <int B, int E, typename F>
@@ -57,9 +75,14 @@ __device__ __forceinline__ void ff_static_for(F&& f) {
   }
 }
 
-// LNF: apply LayerNorm to the resident rows; OVL: interleave the GEGLU arithmetic of step j-1 with the MFMAs of step j
-template <typename T, bool LNF, bool OVL>
+// LNF: apply LayerNorm to the resident rows.  VAR bits: 1 = GEGLU arithmetic of step j-1 NOT interleaved with the MFMAs of
+// step j (A/B); timing ablations with wrong results: 4 = no GEGLU arithmetic, 8 = no
+// second GEMM, 32 = no first GEMM
+template <typename T, bool LNF, int VAR>
 __global__ __launch_bounds__(256) void ff320_kernel(const FfArgs p) {
+  constexpr bool OVL = !(VAR & 1);
+  constexpr int PF = 6;                            // W1 fragment reads in flight ahead of their MFMA (one wave per SIMD:
+                                                   // nothing else hides the LDS latency)
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -68,6 +91,17 @@ __global__ __launch_bounds__(256) void ff320_kernel(const FfArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if constexpr ((VAR & 64) != 0) {
+      if (blockIdx.x == gridDim.x / 2 && wave_u == 0 && n_stamp < 60) {
+        const long long tsv = (long long)__builtin_amdgcn_s_memtime();
+        if (lane == 0) p.dbg[n_stamp] = tsv;
+        ++n_stamp;
+      }
+    }
+  };
+  stamp();
   const int hi = lane >> 5, l31 = lane & 31;
   const int m0 = blockIdx.x * 128 + wave_u * 32;
   const int m = m0 + l31;
@@ -77,18 +111,18 @@ __global__ __launch_bounds__(256) void ff320_kernel(const FfArgs p) {
   // ---- weight stream: step s = bytes [s * 32 KB, +32 KB) of the packed image, lane-linear ----
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wpack), 0, FF_NSTEP * FF_CHUNK, 0x00020000);
   const int w_voff = lane * 16;
-  int issued = 0;
-  auto issue_next = [&]() {
-    const int dst = (issued % FF_RING) * FF_CHUNK + wave_u * 1024;
-    const int src = issued * FF_CHUNK + wave_u * 1024;
-#pragma unroll
-    for (int i = 0; i < FF_DMA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(lds + dst + i * 4096), 16, w_voff,
-                                               src + i * 4096, 0, 0);
-    ++issued;
+  // chunk c (0 / 1) of pair t: W1 pieces -> W1 ring slot t % 2, W2 / b1 pieces -> W2 ring slot t % 3.  Piece i of a wave covers
+  // bytes [(4 i + wave) KB, + 1 KB) of the chunk image: i < 5 is W1, i >= 5 the W2 / b1 part.
+  auto issue_piece = [&](const int i, const int t, const int c) {
+    const int src = (2 * t + c) * FF_CHUNK + (i * 4 + wave_u) * 1024;
+    const int dst = i < FF_DMA_W1 ? ((t % FF_W1_RING) * 2 + c) * FF_W1_BYTES + (i * 4 + wave_u) * 1024
+                                  : FF_OFF_W2 + ((t % FF_W2_RING) * 2 + c) * FF_W2_SLOT + ((i - FF_DMA_W1) * 4 + wave_u) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(lds + dst), 16, w_voff, src, 0, 0);
   };
-  issue_next();
-  issue_next();
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int i = 0; i < FF_DMA; ++i) issue_piece(i, 0, c);
 
   // ---- resident rows: B operand fragments of LayerNorm(x): lane holds x[m][k16 * 16 + hi * 8 .. +8] ----
   V8 af[FF_K16];
@@ -126,8 +160,8 @@ __global__ __launch_bounds__(256) void ff320_kernel(const FfArgs p) {
   int fo[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) fo[kk] = l31 * 128 + ((kk * 2) ^ xsw) * 16;
-  const int w2o = FF_W1_BYTES + l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) * 16);
-  const int b1o = FF_B1_OFF + hi * 64;
+  const int w2o = l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) * 16);       // inside a W2 slot
+  const int b1o = FF_W2_BYTES + hi * 64;
 
   const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   f32x16 yacc[10];
@@ -136,65 +170,82 @@ __global__ __launch_bounds__(256) void ff320_kernel(const FfArgs p) {
 
   typedef const __attribute__((address_space(3))) V8* ldsv8;
   typedef const __attribute__((address_space(3))) f32x4* ldsf4;
+  stamp();
 
   // GEGLU of one accumulator element pair: value register E, gate register E + 8 (common.h gelu_u: the scales ride in b1)
-  f32x4 cv0, cv1, cg0, cg1;
-  float hf[8];
-  auto geglu_elem = [&](auto e_c, const f32x16& acc) {
+  f32x4 cb[2][4];                 // [chunk of the pair][value 0..3, value 8..11, gate 0..3, gate 8..11]
+  float hf[16];
+  auto geglu_elem = [&](auto e_c, const f32x16& acc, const int c) {
     constexpr int E = decltype(e_c)::value;
-    const float bv = E < 4 ? cv0[E & 3] : cv1[E & 3];
-    const float bg = E < 4 ? cg0[E & 3] : cg1[E & 3];
+    const float bv = cb[c][E >> 2][E & 3];
+    const float bg = cb[c][2 + (E >> 2)][E & 3];
     const float hv = __builtin_fmaf(GELU_U_INV, acc[E], bv);
     const float gu = __builtin_fmaf(GELU_U_SCALE, acc[E + 8], bg);
-    hf[E] = hv * gelu_u(gu);
+    hf[c * 8 + E] = hv * gelu_u(gu);
   };
-  auto pack_h = [&]() {
+  auto pack_h = [&](const int c) {
     V8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(hf[e]);
+    for (int e = 0; e < 8; ++e) v[e] = from_f32<T>(hf[c * 8 + e]);
     return v;
   };
 
-  // ---- one step: W1 block of step `s` -> acc_cur (20 MFMAs), with the GEGLU arithmetic of the previous step's accumulator in
-  // between (OVL); then the previous step's 8 products against its W2 slice (10 MFMAs into yacc) ----
-  auto step = [&](auto prev_c, auto cur_c, const int s, f32x16& acc_cur, const f32x16& acc_prev) {
-    constexpr bool PREV = decltype(prev_c)::value;      // a step s - 1 exists: finish it
-    constexpr bool CUR = decltype(cur_c)::value;        // a step s exists (false: drain only)
-    if (CUR) {
-      // chunk s has landed when at most the 8 DMAs of chunk s + 1 are younger
-      if (issued > s + 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();      // chunk s visible to every wave; every wave is done with chunk s - 2 (slot of chunk s + 2)
-      if (issued < FF_NSTEP) issue_next();
-    }
-    const unsigned slot = (unsigned)((s % FF_RING) * FF_CHUNK);
-    const unsigned pslot = (unsigned)(((s + FF_RING - 1) % FF_RING) * FF_CHUNK);
-    const lds_u8* const sw0 = lds + ((slot + (unsigned)fo[0]) & 0x3FFF0u);
-    const lds_u8* const sw1 = lds + ((slot + (unsigned)fo[1]) & 0x3FFF0u);
-    const lds_u8* const sw2 = lds + ((slot + (unsigned)fo[2]) & 0x3FFF0u);
-    const lds_u8* const sw3 = lds + ((slot + (unsigned)fo[3]) & 0x3FFF0u);
-    const lds_u8* const pw2 = lds + ((pslot + (unsigned)w2o) & 0x3FFF0u);
+  // ---- one step = a PAIR of 16-column chunks (2t, 2t + 1).  Why a pair: a 20-MFMA chain on ONE accumulator with anything
+  // issued between its links loses the back-to-back forwarding of dependent MFMAs (~40 cycles per link, measured: the
+  // single-chunk form of this kernel ran 2900 cycles per 30 MFMAs with matrix pipe, VALU and LDS each under a third busy).
+  // Two chunks give two independent chains that alternate, and every gap then separates MFMAs on different accumulators.
+  //   before the barrier   W2 fragments + b1 of pair t-1 -> registers (their slots are then free for the DMA of pair t+1)
+  //   barrier              pair t visible (both chunks were issued during step t-1: vmcnt(0))
+  //   first GEMM           2 x 20 MFMAs (K = 320) alternating between the chunks, rolling W1 fragment reads, the GEGLU
+  //                        arithmetic of pair t-1 (16 elements per lane) in between
+  //   second GEMM          pair t-1: 2 x 10 MFMAs into the 10 output accumulators, the 16 DMA issues of pair t+1 in between
+  auto step = [&](auto prev_c, auto cur_c, const int t, f32x16& a0, f32x16& a1, const f32x16& p0, const f32x16& p1) {
+    constexpr bool PREV = decltype(prev_c)::value;
+    constexpr bool CUR = decltype(cur_c)::value;
+    const unsigned w1s = (unsigned)((t % FF_W1_RING) * 2 * FF_W1_BYTES);
+    const unsigned w2s = (unsigned)(FF_OFF_W2 + ((t + FF_W2_RING - 1) % FF_W2_RING) * 2 * FF_W2_SLOT);      // pair t-1
     if (PREV) {
-      const lds_u8* const pb = lds + ((pslot + (unsigned)b1o) & 0x3FFF0u);
-      cv0 = *(ldsf4)(pb); cv1 = *(ldsf4)(pb + 16); cg0 = *(ldsf4)(pb + 32); cg1 = *(ldsf4)(pb + 48);
+      const lds_u8* const pb0 = lds + ((w2s + (unsigned)b1o) & 0x3FFF0u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { cb[0][i] = *(ldsf4)(pb0 + 16 * i); cb[1][i] = *(ldsf4)(pb0 + FF_W2_SLOT + 16 * i); }
+    }
+    if (t < 6) stamp();
+    if (CUR) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // pair t (issued during step t-1) has landed
+      if (t < 6) stamp();
+      __builtin_amdgcn_s_barrier();                          // ... for every wave; every wave is done with pair t-1's W1 and pair t-2's W2
+    }
+    if (t < 6) stamp();
+    const lds_u8* sw[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      sw[0][kk] = lds + ((w1s + (unsigned)fo[kk]) & 0x3FFF0u);
+      sw[1][kk] = sw[0][kk] + FF_W1_BYTES;
     }
     if (CUR) {
-      V8 fr[3];
-#define FF_LOADW(set, k) fr[set] = *(ldsv8)((((k) & 3) == 0 ? sw0 : ((k) & 3) == 1 ? sw1 : ((k) & 3) == 2 ? sw2 : sw3) + ((k) >> 2) * 4096)
-      FF_LOADW(0, 0);
-      FF_LOADW(1, 1);
+      constexpr int PFK = PF / 2;           // k16 steps in flight ahead (two fragments each)
+      V8 fr[2][PFK];
+#define FF_LOADW(k) { fr[0][(k) % PFK] = *(ldsv8)(sw[0][(k) & 3] + ((k) >> 2) * 4096); fr[1][(k) % PFK] = *(ldsv8)(sw[1][(k) & 3] + ((k) >> 2) * 4096); }
+      ff_static_for<0, PFK>([&](auto kc) { constexpr int k = decltype(kc)::value; FF_LOADW(k); });
       ff_static_for<0, FF_K16 / 2>([&](auto rc) {
         constexpr int R = decltype(rc)::value;
+        ff_static_for<0, 2>([&](auto kkc) {
+          constexpr int k = 2 * R + decltype(kkc)::value;
+          if constexpr (!(VAR & 32)) {
+            a0 = Vec<T>::mfma32(fr[0][k % PFK], af[k], k == 0 ? zero16 : a0);
+            a1 = Vec<T>::mfma32(fr[1][k % PFK], af[k], k == 0 ? zero16 : a1);
+          } else {
+            if (k == 0) { a0 = zero16; a1 = zero16; }
+            a0[k & 15] += to_f32(fr[0][k % PFK][0]); a1[k & 15] += to_f32(fr[1][k % PFK][0]);
+          }
+          if constexpr (k + PFK < FF_K16) { FF_LOADW(k + PFK); }
+        });
+        if constexpr (PREV && OVL && R < 8 && !(VAR & 4)) {
+          geglu_elem(std::integral_constant<int, R>{}, p0, 0);
+          geglu_elem(std::integral_constant<int, R>{}, p1, 1);
+          asm volatile("" : "+v"(hf[R]), "+v"(hf[8 + R]));      // opaque uses INSIDE the region: without them the arithmetic sinks behind the last MFMA
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int k = 2 * R + kk;
-          if (k + 2 < FF_K16) { FF_LOADW((k + 2) % 3, k + 2); }
-          acc_cur = Vec<T>::mfma32(fr[k % 3], af[k], k == 0 ? zero16 : acc_cur);
-        }
-        if constexpr (PREV && OVL && R < 8) {
-          geglu_elem(std::integral_constant<int, R>{}, acc_prev);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
+          for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
           }
@@ -203,31 +254,52 @@ __global__ __launch_bounds__(256) void ff320_kernel(const FfArgs p) {
       });
 #undef FF_LOADW
     }
+    if (t < 6) stamp();
     if (PREV) {
-      if (!(OVL && CUR)) ff_static_for<0, 8>([&](auto ec) { geglu_elem(ec, acc_prev); });
-      const V8 pf = pack_h();
-      V8 w2f[2];
-      w2f[0] = *(ldsv8)(pw2);
+      if constexpr (VAR & 4) {
 #pragma unroll
-      for (int b = 0; b < 10; ++b) {
-        if (b + 1 < 10) w2f[(b + 1) & 1] = *(ldsv8)(pw2 + (b + 1) * 1024);
-        yacc[b] = Vec<T>::mfma32(w2f[b & 1], pf, yacc[b]);
+        for (int e = 0; e < 8; ++e) { hf[e] = p0[e] + p0[e + 8]; hf[8 + e] = p1[e] + p1[e + 8]; }
+      } else if (!(OVL && CUR)) {
+        ff_static_for<0, 8>([&](auto ec) { geglu_elem(ec, p0, 0); geglu_elem(ec, p1, 1); });
       }
+      const V8 pf0 = pack_h(0), pf1 = pack_h(1);
+      // second GEMM of pair t-1: W2 fragments straight from the W2 ring (3 in flight), the 16 DMA issues of pair t+1 in between.
+      // The DMA is issued unconditionally: past the end of the image the descriptor's bounds check makes it a zero fill.
+      const lds_u8* const pw = lds + ((w2s + (unsigned)w2o) & 0x3FFF0u);
+      V8 w2f[3];
+#define FF_LOADW2(j) w2f[(j) % 3] = *(ldsv8)(pw + ((j) / 10) * FF_W2_SLOT + ((j) % 10) * 1024)
+      FF_LOADW2(0); FF_LOADW2(1); FF_LOADW2(2);
+      ff_static_for<0, 20>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (!(VAR & 8)) yacc[j % 10] = Vec<T>::mfma32(w2f[j % 3], j < 10 ? pf0 : pf1, yacc[j % 10]);
+        else yacc[j % 10][0] += to_f32(w2f[j % 3][0]) * to_f32((j < 10 ? pf0 : pf1)[j & 7]);
+        if constexpr (j + 3 < 20) { FF_LOADW2(j + 3); }
+        if constexpr (CUR && j < 2 * FF_DMA) issue_piece(j % FF_DMA, t + 1, j / FF_DMA);
+      });
+#undef FF_LOADW2
+    } else if (CUR) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < FF_DMA; ++i) issue_piece(i, t + 1, c);
     }
   };
 
-  f32x16 acc_a, acc_b;
+  f32x16 acc_a0, acc_a1, acc_b0, acc_b1;
   {
     using TT = std::true_type;
     using FF = std::false_type;
-    step(FF{}, TT{}, 0, acc_a, acc_b);
-    int s = 1;
-    for (; s + 1 < FF_NSTEP; s += 2) {          // two steps per trip: the accumulators alternate by name
-      step(TT{}, TT{}, s, acc_b, acc_a);
-      step(TT{}, TT{}, s + 1, acc_a, acc_b);
+    constexpr int NP = FF_NSTEP / 2;          // 40 pairs
+    step(FF{}, TT{}, 0, acc_a0, acc_a1, acc_b0, acc_b1);
+    for (int t = 1; t + 1 < NP; t += 2) {     // two steps per trip: the accumulator sets alternate by name
+      step(TT{}, TT{}, t, acc_b0, acc_b1, acc_a0, acc_a1);
+      step(TT{}, TT{}, t + 1, acc_a0, acc_a1, acc_b0, acc_b1);
     }
-    step(TT{}, TT{}, FF_NSTEP - 1, acc_b, acc_a);      // FF_NSTEP is even: the last step lands in acc_b
-    step(TT{}, FF{}, FF_NSTEP, acc_a, acc_b);          // drain: GEGLU + second GEMM of the last step
+    step(TT{}, TT{}, NP - 1, acc_b0, acc_b1, acc_a0, acc_a1);           // NP is even: the last pair lands in acc_b
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the zero-fill DMAs behind the last pair
+    stamp();
+    step(TT{}, FF{}, NP, acc_a0, acc_a1, acc_b0, acc_b1);               // drain: GEGLU + second GEMM of the last pair
+    stamp();
   }
 
   // ---- epilogue: y = yacc + b2 + res; lane owns row m, columns blk * 32 + 8 g + 4 hi + j; pairs of 4-column groups are merged
@@ -258,31 +330,49 @@ __global__ __launch_bounds__(256) void ff320_kernel(const FfArgs p) {
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp();
 }
 
-static int g_ff_variant = 1;          // hallo_set_option("ff_fused", 0 | 1 | 2): 0 = callers use the two-GEMM path, 1 = overlapped, 2 = serial (A/B)
+static long long* g_ff_dbg = nullptr;      // hallo_ff320_debug_buffer (ablation builds)
+// hallo_set_option("ff_fused", v): 0 (default) = host code keeps the two-hallo_gemm path, 1 = FeedForward.run_ln of 320-wide blocks
+// calls this kernel, 2.. = A/B / ablation forms (-DHALLO_ABLATIONS).  Default 0 because the kernel, while correct and
+// bit-reproducible, is SLOWER than the pair it fuses: 219 us against 193 us at 65536 rows (tools/cbench ff, MI355X) -- see the
+// measurement notes at the end of the header comment.
+static int g_ff_variant = 0;
 int ff_fused_variant() { return g_ff_variant; }
 void set_ff_fused_variant(int v) { g_ff_variant = v; }
 
-template <typename T, bool LNF, bool OVL>
+template <typename T, bool LNF, int VAR>
 static int launch_ff_one(const FfArgs& a, hipStream_t st) {
   static bool attr_done[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -19;
   if (!attr_done[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ff320_kernel<T, LNF, OVL>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ff320_kernel<T, LNF, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS) != hipSuccess)
       return -12;
     attr_done[dev] = true;
   }
-  hipLaunchKernelGGL((ff320_kernel<T, LNF, OVL>), dim3((a.M + 127) / 128), dim3(256), FF_LDS, st, a);
+  hipLaunchKernelGGL((ff320_kernel<T, LNF, VAR>), dim3((a.M + 127) / 128), dim3(256), FF_LDS, st, a);
   return 0;
 }
 
 template <typename T>
 static int launch_ff(const FfArgs& a, bool lnf, hipStream_t st) {
   int rc;
-  if (g_ff_variant == 2) rc = lnf ? launch_ff_one<T, true, false>(a, st) : launch_ff_one<T, false, false>(a, st);
-  else rc = lnf ? launch_ff_one<T, true, true>(a, st) : launch_ff_one<T, false, true>(a, st);
+#ifdef HALLO_ABLATIONS
+  if (g_ff_variant >= 2 && lnf) {
+    switch (g_ff_variant) {
+      case 2: rc = launch_ff_one<T, true, 1>(a, st); break;
+      case 4: rc = launch_ff_one<T, true, 4>(a, st); break;
+      case 5: rc = launch_ff_one<T, true, 8>(a, st); break;
+      case 7: rc = launch_ff_one<T, true, 32>(a, st); break;
+      case 9: rc = launch_ff_one<T, true, 64>(a, st); break;
+      default: rc = launch_ff_one<T, true, 4 + 8>(a, st); break;
+    }
+  } else
+#endif
+  rc = lnf ? launch_ff_one<T, true, 0>(a, st) : launch_ff_one<T, false, 0>(a, st);
   if (rc) return rc;
   HALLO_CHECK_LAUNCH();
   return 0;
@@ -291,6 +381,10 @@ static int launch_ff(const FfArgs& a, bool lnf, hipStream_t st) {
 }  // namespace hallo
 
 using namespace hallo;
+
+#ifdef HALLO_ABLATIONS
+extern "C" void hallo_ff320_debug_buffer(long long* p) { g_ff_dbg = p; }
+#endif
 
 extern "C" int64_t hallo_ff320_pack_bytes(void) { return (int64_t)FF_NSTEP * FF_CHUNK; }
 
@@ -302,6 +396,7 @@ extern "C" int hallo_ff320(const void* x, int64_t ldx, const void* res, int64_t 
   if (!al(x, 16) || !al(y, 16) || !al(res, 8) || !al(wpack, 16) || !al(b2, 8)) return -22;
   FfArgs a;
   a.x = x; a.ldx = ldx; a.res = res; a.ldr = ldr; a.y = y; a.ldy = ldy; a.wpack = wpack; a.b2 = b2; a.M = (int)M; a.ln_eps = ln_eps;
+  a.dbg = g_ff_dbg;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == DT_F16) return launch_ff<_Float16>(a, layernorm != 0, st);
   if (dtype == DT_BF16) return launch_ff<__bf16>(a, layernorm != 0, st);

@@ -61,7 +61,12 @@ def _copy_into(dst, src):
     if torch.is_tensor(dst):
         if dst.shape != src.shape or dst.dtype != src.dtype:
             raise ValueError("a cached per-clip constant changed shape between clips of one graph key")
-        dst.copy_(src)
+        if any(st == 0 and sz > 1 for st, sz in zip(dst.stride(), dst.shape)):
+            # a broadcast (expanded) view, e.g. the face tokens repeated over the frames: write its un-broadcast slice
+            idx = tuple(slice(0, 1) if (st == 0 and sz > 1) else slice(None) for st, sz in zip(dst.stride(), dst.shape))
+            dst[idx].copy_(src[idx])
+        else:
+            dst.copy_(src)
     elif isinstance(dst, (tuple, list)):
         if len(dst) != len(src):
             raise ValueError("a cached per-clip constant changed arity between clips of one graph key")

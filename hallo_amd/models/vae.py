@@ -41,13 +41,20 @@ class VaeAttention(Attention):
         # V^T[b] = Wv . g[b]^T + bv  -> the "weight" operand of the P.V GEMM
         vt = torch.empty((n, Cd, L), device=x.device, dtype=x.dtype)
         ops.gemm_batched(self.to_v.weight.unsqueeze(0).expand(n, Cd, Cd), g, vt, bias=self.to_v.bias, bias_per_row=True)
-        s = torch.empty((n, L, L), device=x.device, dtype=torch.float32)
-        ops.gemm_batched(q, k, s, out_f32=True)
-        p = torch.empty((n, L, L), device=x.device, dtype=x.dtype)
-        ops.softmax_rows(s, p, Cd ** -0.5)
+        # scores of a group of frames at a time: the fp32 [L, L] matrices of ALL frames would be 1 GB at 512 x 512 x 16 frames and
+        # 8 GB at 768 x 768 x 24; SCORE_BYTES bounds the buffer, the frames are independent
+        nc = max(1, min(n, self.SCORE_BYTES // (L * L * 4)))
+        s = torch.empty((nc, L, L), device=x.device, dtype=torch.float32)
+        p = torch.empty((nc, L, L), device=x.device, dtype=x.dtype)
         o = torch.empty((n, L, Cd), device=x.device, dtype=x.dtype)
-        ops.gemm_batched(p, vt, o)
+        for f0 in range(0, n, nc):
+            c = min(nc, n - f0)
+            ops.gemm_batched(q[f0:f0 + c], k[f0:f0 + c], s[:c], out_f32=True)
+            ops.softmax_rows(s[:c], p[:c], Cd ** -0.5)
+            ops.gemm_batched(p[:c], vt[f0:f0 + c], o[f0:f0 + c])
         return self.out(o, residual=x)
+
+    SCORE_BYTES = 1 << 30
 
 
 class _MidBlock(nn.Module):

@@ -118,11 +118,11 @@ def test_every_entry_point_rejects_bad_arguments(lib):
     res['ff_null']=lib.hallo_ff320(N,320,N,320,N,320,N,N,128,1,1e-5,0,N)
     res['ff_ld']=lib.hallo_ff320(p,324,p,320,p,320,p,p,128,1,1e-5,0,N)          # ldx not a multiple of 8
     res['ff_dtype']=lib.hallo_ff320(p,320,p,320,p,320,p,p,128,1,1e-5,7,N)
-    res['ff_opt']=lib.hallo_set_option(b"ff_fused",3)
+    res['ff_opt']=lib.hallo_set_option(b"ff_fused",10)
     res['rsdbg_gated']=lib.hallo_set_option(b"gemm_rs_dbg",1)                    # timing ablations need a -DHALLO_ABLATIONS build
     res['opt_unknown']=lib.hallo_set_option(b"nope",1); res['get_unknown']=lib.hallo_get_option(b"nope")
     bad = {k: v for k, v in res.items() if v != -22}
     assert not bad, bad
     assert len(res) >= 36
     assert lib.hallo_groupnorm_chunks(4096) > 0
-    assert lib.hallo_ff320_pack_bytes() == 80 * 32768 and lib.hallo_get_option(b"gemm_rs_dbg") == 0 and lib.hallo_get_option(b"ff_fused") == 1
+    assert lib.hallo_ff320_pack_bytes() == 80 * 32768 and lib.hallo_get_option(b"gemm_rs_dbg") == 0 and lib.hallo_get_option(b"ff_fused") == 0

@@ -25,7 +25,7 @@ def test_full_size_bodies_replay(Fz, dtype):
         Fz.test_full_unet3d_forward(dtype, case, rep)
     Fz.test_full_vae(dtype, rep)
     Fz.test_full_pipeline_config0_geometry(dtype, rep)
-    Fz.test_zz_release_cache()
+    Fz.test_zz_release_cache(rep)
     assert len(rep) == 1 + len(Fz.CASES) + 2 + 2 and all(r["arch"] == "small" for r in rep)
 
 

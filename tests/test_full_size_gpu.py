@@ -36,6 +36,7 @@ TOL_BANK = {torch.float16: 5e-3, torch.bfloat16: 2e-2}
 TOL_VAE = {torch.float16: 5e-3, torch.bfloat16: 3e-2}
 
 _CACHE = {}
+GOLDEN_LOG = []          # one record per stored-output lookup (written into the parity report by test_zz_release_cache)
 
 
 def _arch():
@@ -63,10 +64,11 @@ def _native(dtype):
 
 
 def fingerprint(tensors):
-    """Order-independent fingerprint of a list of fp32 tensors: the exact int64 sum of their bit patterns (associative,
-    so thread count / vector width cannot change it) + fp64 moments.  `same_data` accepts equal bit sums, or moments equal
-    to 1e-9 relative: a handful of synthetic weights one bf16 ulp apart on another CPU's randn (nothing against the 1e-2
-    tolerances) must not throw the stored oracle outputs away, a different seed or shape must."""
+    """Fingerprint of a list of fp32 tensors: element count, the exact int64 sum of the bit patterns (associative: thread count /
+    vector width cannot change it) and fp64 moments.  `same_data` accepts equal bit sums, or moments equal to 1e-4 relative:
+    torch.randn's CPU kernels differ in the last ulp between vector ISAs (AVX2 / AVX-512 hosts), which moves a few hundred of
+    the 4e7 bf16-rounded synthetic inputs by one bf16 ulp -- nothing against tolerances of 1e-2, and no reason to throw a
+    stored oracle output away -- while another seed or shape moves the moments by percent."""
     bits = s1 = s2 = 0
     n = 0
     for t in tensors:
@@ -83,8 +85,8 @@ def same_data(a, b):
         return False
     if a["bits"] == b["bits"]:
         return True
-    close = lambda x, y: abs(x - y) <= 1e-9 * max(abs(x), abs(y), 1e-30)
-    return close(a["sum"], b["sum"]) and close(a["abs"], b["abs"])
+    close = lambda x, y, ref: abs(x - y) <= 1e-4 * ref
+    return close(a["sum"], b["sum"], max(a["abs"], 1e-30)) and close(a["abs"], b["abs"], max(a["abs"], 1e-30))
 
 
 def _weights_fp(names):
@@ -112,8 +114,11 @@ def golden_lookup(key, weight_nets, inputs):
     m = g.get("meta", {}).get(key) if g else None
     if m is None:
         return None
-    if not (same_data(m["weights"], _weights_fp(weight_nets)) and same_data(m["inputs"], fingerprint(inputs))):
-        print(f"golden[{key}]: fingerprint mismatch -> evaluating the oracle here")
+    wf, inf = _weights_fp(weight_nets), fingerprint(inputs)
+    GOLDEN_LOG.append({"key": key, "weights_here": wf, "weights_stored": m["weights"], "inputs_here": inf, "inputs_stored": m["inputs"],
+                       "weights_exact": wf["bits"] == m["weights"]["bits"], "inputs_exact": inf["bits"] == m["inputs"]["bits"]})
+    if not (same_data(m["weights"], wf) and same_data(m["inputs"], inf)):
+        print(f"golden[{key}]: fingerprint mismatch -> evaluating the oracle here", GOLDEN_LOG[-1])
         return None
     return {a: torch.from_numpy(g["z"][f"{key}/{a}"].astype("float32")) for a in m["arrays"]}
 
@@ -410,8 +415,11 @@ def test_full_pipeline_config0_ten_steps(dtype, report):
     assert p >= 35.0
 
 
-def test_zz_release_cache():
+def test_zz_release_cache(report):
     """Last in the file: drop the ~15 GB of cached oracle / native nets before the remaining test modules run."""
+    for rec in GOLDEN_LOG:
+        report.append(dict(rec, test="golden_lookup"))
+    del GOLDEN_LOG[:]
     _CACHE.clear()
     if DEV != "cpu":
         torch.cuda.empty_cache()

@@ -313,3 +313,93 @@ def test_gemm_big_tile_layernorm(dtype, M, Cd, geglu, report):
     nh = torch.nn.functional.layer_norm(x.float(), (Cd,), gamma.float(), beta.float(), 1e-5)
     ref = ops_ref.geglu(nh, w, b) if geglu else nh @ w.float().t() + b.float()
     _check(f"gemm3_ln[{M},{Cd},{'geglu' if geglu else 'qkv'}]", out, ref, dtype, report)
+
+
+# --------------------------------------------------------------------------------------------
+# Row counts of BASELINE.json configs[2] (512 x 512 x 16 frames with CFG: 2 x 16 x 4096 = 131 072 rows, 2 x 18 x 4096 =
+# 147 456 in the motion modules) and configs[4] (768 x 768 x 24 frames: 24 x 9216 = 221 184): they change gemm_rs2.hip's
+# round / N-slice split and the big tile's auto rule.
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,kind", [(131072, "qkv"), (147456, "qkv"), (221184, "qkv"), (131072, "geglu"), (147456, "geglu"),
+                                    (221184, "geglu")])
+def test_gemm_rs2_cfg_and_768_row_counts(dtype, M, kind, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(M + len(kind))
+    K = 320
+    x = _rand((M, K), dtype, g) * 1.3 + 0.4
+    gamma = (1.0 + 0.1 * torch.randn((K,), generator=g)).to(dtype).to(_dev())
+    beta = _rand((K,), dtype, g, 0.1)
+    N = 960 if kind == "qkv" else 1280
+    w = _rand((N if kind == "qkv" else 2 * N, K), dtype, g, K ** -0.5)
+    b = _rand((w.shape[0],), dtype, g, 0.1)
+    wf, cs, bf = ops.fold_layernorm(gamma, beta, w, b)
+    geglu = kind == "geglu"
+    assert ops.ln_stats(x, N, 1e-5, geglu=geglu, lead_cols=320 if not geglu else 0) is None      # the row-stationary kernel takes it
+    out = ops.gemm(x, wf, bf, geglu=geglu, ln_colsum=cs, ln_eps=1e-5, lead_cols=0 if geglu else 320, lead_alpha=0.25)
+    assert _took_rs(ops), ops.get_option("last_gemm_kernel")
+    # fp32 expression in row slabs (the fp32 intermediate of the full problem would be 2.3 GB)
+    ref = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    for r0 in range(0, M, 32768):
+        nh = torch.nn.functional.layer_norm(x[r0:r0 + 32768].float(), (K,), gamma.float(), beta.float(), 1e-5)
+        if geglu:
+            ref[r0:r0 + 32768] = ops_ref.geglu(nh, w, b)
+        else:
+            ref[r0:r0 + 32768] = nh @ w.float().t() + b.float()
+    if not geglu:
+        ref[:, :320] *= 0.25
+    _check(f"gemm_rs2_rows[{M},{kind}]", out, ref, dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,kind", [
+    (131072, 320, 1280, "res"),       # configs[2] L0 ff.net[2] (the big tile's 512 workgroups = 2 rounds)
+    (221184, 320, 1280, "res"),       # configs[4] L0 ff.net[2]
+    (32768, 640, 2560, "res"),        # configs[2] L1 ff.net[2]
+    (55296, 2560, 640, "geglu-ln"),   # configs[4] L1 GEGLU with the LayerNorm epilogue (24 x 48 x 48 rows)
+    (147456, 320, 320, "res"),        # configs[2] motion-module to_out + residual
+])
+def test_gemm_big_tile_cfg_and_768_row_counts(dtype, M, N, K, kind, report):
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    a = _rand((M, K), dtype, g)
+    if kind == "geglu-ln":
+        gamma = (1.0 + 0.1 * torch.randn((K,), generator=g)).to(dtype).to(_dev())
+        beta = _rand((K,), dtype, g, 0.1)
+        w = _rand((2 * N, K), dtype, g, K ** -0.5)
+        b = _rand((2 * N,), dtype, g, 0.1)
+        wf, cs, bf = ops.fold_layernorm(gamma, beta, w, b)
+        out = ops.gemm(a, wf, bf, geglu=True, ln_colsum=cs, ln_eps=1e-5, ln_stats=ops.ln_stats(a, N, 1e-5, geglu=True))
+        ref = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        for r0 in range(0, M, 16384):
+            nh = torch.nn.functional.layer_norm(a[r0:r0 + 16384].float(), (K,), gamma.float(), beta.float(), 1e-5)
+            ref[r0:r0 + 16384] = ops_ref.geglu(nh, w, b)
+    else:
+        w = _rand((N, K), dtype, g, K ** -0.5)
+        b = _rand((N,), dtype, g)
+        res = _rand((M, N), dtype, g)
+        out = ops.gemm(a, w, b, residual=res)
+        ref = ops_ref.linear(a, w, b) + res.float()
+    _check(f"gemm_rows[{M},{N},{K},{kind}]", out, ref, dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_l0_768_two_segment(dtype, report):
+    """hd 40 x 8 heads at 768 x 768: Lq = 9216, K/V = [self 9216 ; reference bank 9216] (BASELINE.json configs[4]'s L0
+    launch, 144 key tiles per segment), 2 frames with the CFG extent, pre-scaled q as the UNet runs it."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(9216)
+    hd, H, L, Fr = 40, 8, 9216, 1
+    Cd = H * hd
+    N = 2 * Fr
+    qkv = _rand((N, L, 3 * Cd), dtype, g)
+    bank_kv = _rand((2, L, 2 * Cd), dtype, g)
+    q, k1, v1 = qkv[:, :, :Cd], qkv[:, :, Cd:2 * Cd], qkv[:, :, 2 * Cd:]
+    k2, v2 = bank_kv[:, :, :Cd], bank_kv[:, :, Cd:]
+    qs = (q.float() * ops.q_scale(hd)).to(dtype)
+    out = ops.attention(qs, k1, v1, H, k2=k2, v2=v2, kv2_batch_div=Fr, kv2_first_batch=Fr, q_prescaled=True)
+    ref = ops_ref.reference_self_attention(qs.float() / ops.q_scale(hd), k1, v1, k2, v2, H, Fr, Fr)
+    _check("attn_L0_768_two_segment_cfg[40,9216,9216+9216]", out, ref, dtype, report)

@@ -439,10 +439,17 @@ static std::vector<uint8_t> ff_pack(const std::vector<uint16_t>& w1f, const std:
   return img;
 }
 
+extern "C" void hallo_ff320_debug_buffer(long long* p) __attribute__((weak));
+
 static int cmd_ff(int argc, char** argv) {
   const int C = 320, I = 1280;
   int M = argc > 0 ? atoi(argv[0]) : 65536, dt = DT_BF16; bool ln = true;
-  for (int i = 1; i < argc; ++i) { std::string a = argv[i]; if (a == "f16") dt = DT_F16; else if (a == "noln") ln = false; }
+  std::vector<int> variants = {1};
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a == "f16") dt = DT_F16; else if (a == "noln") ln = false;
+    else if (a.rfind("v=", 0) == 0) { variants.clear(); for (char* tok = strtok(argv[i] + 2, ","); tok; tok = strtok(nullptr, ",")) variants.push_back(atoi(tok)); }
+  }
   Timer tm;
   uint16_t* X = dalloc<uint16_t>((long)M * C); uint16_t* Y = dalloc<uint16_t>((long)M * C); uint16_t* Y2 = dalloc<uint16_t>((long)M * C);
   uint16_t* Hb = dalloc<uint16_t>((long)M * I);
@@ -479,10 +486,19 @@ static int cmd_ff(int argc, char** argv) {
   float* Href = dalloc<float>((long)rows * I); float* Yref = dalloc<float>((long)rows * C);
   std::vector<float> href((size_t)rows * C); std::vector<uint16_t> out((size_t)M * C), out2((size_t)M * C), outp((size_t)M * C);
   CK(hipMemcpy(outp.data(), Y2, outp.size() * 2, hipMemcpyDeviceToHost));
-  for (int variant = 1; variant <= 2; ++variant) {
-    HK(hallo_set_option("ff_fused", variant));
+  for (int variant : variants) {
+    if (hallo_set_option("ff_fused", variant) != 0) { printf("ff_fused=%d needs a -DHALLO_ABLATIONS build\n", variant); continue; }
     CK(hipMemset(Y, 0xFF, (size_t)M * C * 2));
+    long long* dbg = nullptr;
+    if (variant == 9 && hallo_ff320_debug_buffer) { dbg = dalloc<long long>(64); CK(hipMemset(dbg, 0, 64 * 8)); hallo_ff320_debug_buffer(dbg); }
     fusedk(); CK(hipDeviceSynchronize());
+    if (dbg) {
+      fusedk(); CK(hipDeviceSynchronize());
+      std::vector<long long> hs(64); CK(hipMemcpy(hs.data(), dbg, 64 * 8, hipMemcpyDeviceToHost));
+      printf("ff stamps (s_memtime deltas, cycles): ");
+      for (int i = 1; i < 64 && hs[i]; ++i) printf("%lld ", hs[i] - hs[i - 1]);
+      printf(" | total %lld\n", hs[0] ? [&]{ long long last = 0; for (int i = 0; i < 64; ++i) if (hs[i]) last = hs[i]; return last - hs[0]; }() : 0LL);
+    }
     CK(hipMemcpy(out.data(), Y, out.size() * 2, hipMemcpyDeviceToHost));
     double en = 0, rn = 0, ep = 0; long nan = 0; int nondet = 0;
     for (int part = 0; part < 2; ++part) {
