@@ -321,6 +321,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="A/B: launch every kernel of every UNet evaluation from the host (round-2 behaviour) instead of replaying "
                          "the hipGraph captured in the warm-up clip (FaceAnimatePipeline(use_graph=True))")
+    ap.add_argument("--graph", action="store_true", help="N > 1: replay the captured hipGraph too (default there: eager launches)")
     ap.add_argument("--gather", default=None, choices=["u8", "f32"],
                     help="N > 1: what the per-wave all-gather moves -- u8 (default): the frames converted to the uint8 video bytes on "
                          "the device (hallo_frames_to_uint8 = hallo/utils/util.py:308-312, 12.6 MB per rank at 512x512x16f); f32: "
@@ -368,7 +369,9 @@ def main():
         if args.fp8_proj:
             pipe.denoising_unet.set_fp8_projections(True)
         # one hipGraph of the UNet evaluation, captured during the warm-up clip, replayed for steps 1.. of every clip
-        pipe.use_graph = not args.no_graph and args.warmup > 0
+        # (N > 1: eager unless --graph -- graph capture next to RCCL's watchdog thread could not be tried on this pool's 1-GPU boxes,
+        # and on one GPU the replay measures within 0.5 % of eager launches: profiles/r3_graph_ab.json)
+        pipe.use_graph = not args.no_graph and args.warmup > 0 and (world == 1 or args.graph)
     from hallo_amd.animate.clip_parallel import gather_wave
     gather_u8 = world > 1 and (args.gather or ("f32" if dry else "u8")) == "u8"
     # rank 0 receives the whole wave (one clip per rank) and copies ALL of it to the host

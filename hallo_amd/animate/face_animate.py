@@ -52,7 +52,8 @@ class StepGraph:
 
     def capture(self, fn):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: HIP calls of OTHER host threads (e.g. the RCCL watchdog of a multi-GPU run) must not invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self.out = fn()
         self.graph = g
 

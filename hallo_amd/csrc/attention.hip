@@ -67,9 +67,10 @@ __global__ __launch_bounds__(256, HD <= 40 ? 3 : (HD <= 80 ? 2 : 1)) void attn_k
   // block id -> (batch, head, q block), XCD-contiguous so a (batch, head)'s K/V stays in one L2
   const int nwg = p.batch * p.heads * p.nqb;
   int bid = xcd_remap(blockIdx.x, nwg);
-  const int qb = bid % p.nqb; bid /= p.nqb;
-  const int h = bid % p.heads;
-  const int b = bid / p.heads;
+  int qb, h;
+  if (p.head_fastest) { h = bid % p.heads; bid /= p.heads; qb = bid % p.nqb; bid /= p.nqb; }
+  else { qb = bid % p.nqb; bid /= p.nqb; h = bid % p.heads; bid /= p.heads; }
+  const int b = bid;
 
   const T* __restrict__ Qg = reinterpret_cast<const T*>(p.q) + (long)b * p.q_bs + h * HD;
   const T* __restrict__ K1 = reinterpret_cast<const T*>(p.k1) + (long)b * p.k1_bs + h * HD;
@@ -656,6 +657,7 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const T* __rest
 }
 
 static int g_temporal_mfma = 1;   // hallo_set_option("temporal_mfma", 0 | 1)
+static int g_attn_order = 2;      // hallo_set_option("attn_order", 0 query-block-fastest | 1 head-fastest | 2 auto: head-fastest for K/V of <= 128 rows)
 static int g_attn40 = 1;          // hallo_set_option("attn40", 0 | 1): head-dim-40 pre-scaled-q launches on attention40.hip
 
 }  // namespace hallo
@@ -682,6 +684,7 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
   a.o_rowscale = d->o_rowscale;
   a.rs_hdiv = d->o_rowscale_head_div > 0 ? d->o_rowscale_head_div : d->heads;
   a.rs_stride = d->o_rowscale_stride;
+  a.head_fastest = (g_attn_order == 1 || (g_attn_order == 2 && a.Lkv1 + a.Lkv2 <= 128)) ? 1 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // attention40.hip stages K / V with 16-byte LDS-DMA (buffer addressing drops misaligned low address bits) and stores 16
   // bytes per lane: every K / V base, row and batch stride and the output must be 16-byte aligned, else the generic kernel
@@ -699,11 +702,13 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
 extern "C" int hallo_get_option_attn(const char* name) {
   if (name && !strcmp(name, "attn40")) return g_attn40;
   if (name && !strcmp(name, "temporal_mfma")) return g_temporal_mfma;
+  if (name && !strcmp(name, "attn_order")) return g_attn_order;
   return -22;
 }
 
 extern "C" int hallo_set_option_attn(const char* name, int value) {
   if (name && !strcmp(name, "temporal_mfma")) { if (value < 0 || value > 1) return -22; g_temporal_mfma = value; return 0; }
+  if (name && !strcmp(name, "attn_order")) { if (value < 0 || value > 2) return -22; g_attn_order = value; return 0; }
   if (name && !strcmp(name, "attn40")) { if (value < 0 || value > 8) return -22; g_attn40 = value; set_attn40_variant(value); return 0; }
   return -22;
 }

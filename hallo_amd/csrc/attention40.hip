@@ -75,9 +75,10 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   // neighbouring HEADS of one frame, whose 80-byte K / V row slices share 128-byte lines.  (Frame-fastest order, which lets
   // three frames share the reference bank's K/V of a head, was measured and is worse: the lines are then used by one head
   // only -- FETCH_SIZE 2.4x / 3.1x the algorithmic reads instead of 1.15x / 2.6x, and the kernel 7 % slower.)
-  const int qb = bid % p.nqb; bid /= p.nqb;
-  const int h = bid % p.heads;
-  const int b = bid / p.heads;
+  int qb, h;
+  if (p.head_fastest) { h = bid % p.heads; bid /= p.heads; qb = bid % p.nqb; bid /= p.nqb; }
+  else { qb = bid % p.nqb; bid /= p.nqb; h = bid % p.heads; bid /= p.heads; }
+  const int b = bid;
 
   const T* __restrict__ Qg = reinterpret_cast<const T*>(p.q) + (long)b * p.q_bs + h * HD;
   const T* __restrict__ K1 = reinterpret_cast<const T*>(p.k1) + (long)b * p.k1_bs + h * HD;

@@ -15,6 +15,10 @@ struct AttnArgs {
   const float* o_rowscale;   // optional fp32 output row scale: o[b, q, head h] *= o_rowscale[(h / rs_hdiv) * rs_stride + b * Lq + q]
   int rs_hdiv;
   long rs_stride;
+  // workgroup order: 0 = query block fastest, then head, then batch (a head's K/V stays in one XCD's L2 while its query blocks
+  // run); 1 = HEAD fastest (short K/V, e.g. the 32 audio / 4 face tokens: nothing to keep, but the heads of one query block
+  // share the 128-byte lines of Q and O -- 80-byte head slices at head dim 40 -- so they should run together)
+  int head_fastest;
 };
 
 // attention40.hip: head dim 40, pre-scaled q.  Returns 0 or a negative status like the other launchers.

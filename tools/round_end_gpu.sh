@@ -3,7 +3,7 @@
 #   gpurun --timeout 900 -- 'bash tools/round_end_gpu.sh r2'
 # 1. like-for-like HBM traffic of the dominant kernels (rocprofv3 --pmc over tools/cbench, one shape and one counter group per pass)
 # 2. bench.py under rocprofv3 --kernel-trace --stats -> bench line + per-kernel stats + launch gaps from the SAME command
-# 3. bench.py unprofiled; the fp8-projection A/B; BASELINE configs[2] (CFG 3.5, 40 steps); __graft_entry__.smoke()
+# 3. bench.py unprofiled (hipGraph replay) and with --no-graph; temporal / token cross-attention timings; the fp8-projection A/B; BASELINE configs[2] (CFG 3.5, 40 steps); __graft_entry__.smoke()
 TAG=${1:-rX}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -15,8 +15,11 @@ timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_prof -o $TAG -
 python tools/prof_db_summary.py gpurun_out/${TAG}_prof/${TAG}_results.db gpurun_out/${TAG}_bench_kernel_stats.csv gpurun_out/${TAG}_bench_launch_gaps.json 2>&1 | tail -2
 rm -rf gpurun_out/${TAG}_prof
 timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_plain.log 2>&1
+timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-graph > gpurun_out/${TAG}_bench_nograph.log 2>&1
+timeout 200 python tools/temporal_bench.py > gpurun_out/${TAG}_temporal_bench.log 2>&1
+timeout 200 python tools/xattn_bench.py > gpurun_out/${TAG}_xattn_bench.log 2>&1
 timeout 200 python bench.py --fp8-proj --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_fp8.log 2>&1
 timeout 200 python bench.py --guidance 3.5 --ddim-steps 40 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_cfg.log 2>&1
 timeout 200 python __graft_entry__.py --smoke > gpurun_out/${TAG}_smoke.log 2>&1
-for f in profiled plain fp8 cfg; do grep -o '"value": [0-9.]*' gpurun_out/${TAG}_bench_$f.log | head -1 | sed "s/^/$f /"; done
+for f in profiled plain nograph fp8 cfg; do grep -o '"value": [0-9.]*' gpurun_out/${TAG}_bench_$f.log | head -1 | sed "s/^/$f /"; done
 tail -1 gpurun_out/${TAG}_smoke.log

@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Token cross-attention timing at the 512x512x16f step's shapes (the three audio branches x 8 heads as one launch, 32 audio
+tokens per frame; the 4 face tokens on the unfused path), A/B over the workgroup order (hallo_set_option("attn_order")):
+bytes = q read + output written (K/V are a few hundred KB)."""
+import os, sys, json
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from hallo_amd import ops
+dev = torch.device("cuda:0")
+out = []
+for dtype in (torch.bfloat16, torch.float16):
+    for (name, n, L, Cq, heads, T) in (("L0 audio 3x8 heads hd 40", 16, 4096, 960, 24, 32), ("L1 audio hd 80", 16, 1024, 1920, 24, 32),
+                                       ("L1 audio half width hd 40", 16, 1024, 960, 24, 32), ("L2 audio hd 160", 16, 256, 3840, 24, 32),
+                                       ("L0 face tokens hd 40", 16, 4096, 320, 8, 4)):
+        q = torch.randn((n, L, Cq), device=dev).to(dtype)
+        kv = torch.randn((n, T, 2 * Cq), device=dev).to(dtype)
+        o = torch.empty((n, L, Cq), device=dev, dtype=dtype)
+        run = lambda: ops.attention(q, kv[:, :, :Cq], kv[:, :, Cq:], heads, out=o, q_prescaled=True)
+        res = {}
+        for order in (0, 2):
+            ops.set_option("attn_order", order)
+            for _ in range(5): run()
+            ts = []
+            for _ in range(7):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(20): run()
+                e.record(); torch.cuda.synchronize()
+                ts.append(s.elapsed_time(e) / 20)
+            res[order] = (sorted(ts)[len(ts) // 2], o.float().clone())
+        ops.set_option("attn_order", 2)
+        by = 2 * 2 * q.numel()
+        same = torch.equal(res[0][1], res[2][1])
+        rec = dict(shape=name, dtype=str(dtype), us_qblock_fastest=round(res[0][0] * 1e3, 1), us_head_fastest=round(res[2][0] * 1e3, 1),
+                   gbs=round(by / res[2][0] / 1e6, 1), hbm_frac=round(by / res[2][0] / 1e6 / 8000, 3), identical_output=same)
+        out.append(rec); print(rec, flush=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "xattn_bench.json"), "w"), indent=1)
