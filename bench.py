@@ -482,25 +482,27 @@ def main():
         out["kernel_ms_per_clip"] = round(tot_ms, 1)
         out["algorithmic_tflop_per_clip"] = round(tot_flop / 1e12, 1)
         # roofline of the dominant kernel SYMBOL (the name rocprofv3 --kernel-trace --stats reports; the committed summary
-        # profiles/r2_bench_kernel_stats.csv is of this same command).  achieved = algorithmic flop (or bytes) of that
+        # profiles/r3_bench_kernel_stats.csv is of this same command).  achieved = algorithmic flop (or bytes) of that
         # symbol's launches / their summed duration, both from events on the launch stream in this run.
         out["kernel_symbols"] = {k: {"ms": round(d["ms"], 2), "launches": d["launches"], "tflops": round(d["tflops"], 1),
                                      "gbs": round(d["gbs"], 1), "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1)}
                                  for k, d in sorted(prof.by_symbol.items(), key=lambda kv: -kv[1]["ms"])[:12]}
         name, d = max(prof.by_symbol.items(), key=lambda kv: kv[1]["ms"])
-        # HBM traffic of the dominant symbol from separate rocprofv3 --pmc passes (tools/pmc_passes.sh + tools/
-        # pmc_traffic_like_for_like.py -> profiles/r2_pmc_traffic.json): FETCH_SIZE / WRITE_SIZE of single launches next to the
+        # HBM traffic of the dominant symbol from separate rocprofv3 --pmc passes (tools/cbench/pmc.sh + tools/
+        # pmc_traffic_cbench.py -> profiles/r3_pmc_traffic.json): FETCH_SIZE / WRITE_SIZE of single launches next to the
         # algorithmic bytes of THOSE launches, per launch shape.  It is a committed measurement of this binary's kernel, not
         # something this run produced (the counter passes cannot run inside a timed bench).
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))
             t = tj.get(name.split("<")[0])
             if t:
                 traffic = {"per_launch_shape": [{k: (round(v) if isinstance(v, float) and v > 1000 else v) for k, v in e.items()} for e in t],
                            "algorithmic_bytes_per_launch_this_run": round(d["bytes"] / d["launches"]),
-                           "source": "profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over "
-                                     "tools/pmc_attn.py; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md)"}
+                           "source": "profiles/r3_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT+MISS, one counter group "
+                                     "per pass over tools/cbench launches of this kernel at these shapes (tools/cbench/pmc.sh, tools/"
+                                     "pmc_traffic_cbench.py; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md).  A committed measurement of "
+                                     "this binary's kernel, not produced by this run"}
         except Exception:
             pass
         # bound by arithmetic intensity against the machine balance (2500 TFLOP/s / 8 TB/s = 312 flop/B): the K = 320

@@ -2,7 +2,8 @@
 """Generate tests/golden/full_size_golden.npz: the fp32 CPU oracle's outputs for the full-width parity cases of
 tests/test_full_size_gpu.py that cost minutes of CPU each:
 
-  unet3d/B2_F16_h64   one UNet3DConditionModel.forward at 512 x 512 x 16 frames with CFG (BASELINE.json configs[2])
+  unet3d/B1_F16_h64   one UNet3DConditionModel.forward at 512 x 512 x 16 frames, B = 1 (the benchmarked configs[1] geometry)
+  unet3d/B2_F16_h64   ... with CFG (BASELINE.json configs[2])
   unet3d/B1_F24_h96   ... at 768 x 768 x 24 frames (configs[4]'s geometry)
   pipeline10          FaceAnimatePipeline.__call__ at 256 x 256 x 8 frames, 10 DDIM steps, CFG 3.5 (configs[0] exactly):
                       per-step latents + decoded frames
@@ -37,7 +38,7 @@ def main(which):
         z = np.load(OUT)
         meta = json.loads(str(z["meta"]))
         arrays = {k: z[k] for k in z.files if k != "meta"}
-    for case in ("512x512x16f-cfg", "768x768x24f"):
+    for case in ("512x512x16f", "512x512x16f-cfg", "768x768x24f"):
         if which and case not in which:
             continue
         B, Fr, h = T.CASES[case]
