@@ -554,7 +554,10 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const T* __rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hi = lane >> 5, l31 = lane & 31;
   const int hgroups = heads >> 2;
-  const long item = blockIdx.x;                       // (b, pixel, head group)
+  // (b, pixel, head group), head group fastest; XCD-contiguous: the head groups of a pixel and its neighbours share the
+  // 128-byte lines of the fused q|k|v rows (1920 bytes per pixel and frame at C = 320), so they should meet in ONE L2 instead
+  // of being dealt round-robin to the 8 XCDs
+  const long item = xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int hg = (int)(item % hgroups);
   const long bp = item / hgroups;                     // b * HW + pixel
   const int pix = (int)(bp % HW);
