@@ -59,6 +59,8 @@ class StepGraph:
 
 
 class FaceAnimatePipeline:
+    MAX_GRAPHS = 2          # captured (geometry, batch, ...) keys kept alive at a time
+
     def __init__(self, vae, reference_unet, denoising_unet, face_locator, image_proj, scheduler, use_graph=False):
         self.vae, self.reference_unet, self.denoising_unet = vae, reference_unet, denoising_unet
         self.face_locator, self.image_proj, self.scheduler = face_locator, image_proj, scheduler
@@ -145,6 +147,12 @@ class FaceAnimatePipeline:
                    bool(getattr(den, "fp8_projections", False)), den.prepare_epoch)
             sg = self._graphs.get(key)
             if sg is None:
+                # graphs of re-prepared weights (another prepare_epoch) point at freed weight images, and every graph pins the
+                # intermediates of one UNet evaluation (GBs): keep the current epoch's, at most MAX_GRAPHS of them
+                for k in [k for k in self._graphs if k[-1] != den.prepare_epoch]:
+                    del self._graphs[k]
+                while len(self._graphs) >= self.MAX_GRAPHS:
+                    del self._graphs[next(iter(self._graphs))]
                 sg = self._graphs[key] = StepGraph(B, Fr, L, C0, dev, dt)
         x_in = sg.x_in if sg is not None else torch.zeros((B * Fr, L, 8), device=dev, dtype=dt)
         x_in.view(B, Fr * L, 8)[:, :, :C_lat] = lat.to(dt)

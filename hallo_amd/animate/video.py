@@ -90,3 +90,65 @@ def generate_video(pipeline, audioproj, source_image_pixels, source_image_face_r
     if output == "uint8":
         raise ops._l.HalloLibraryError("uint8 output runs through hallo_frames_to_uint8 on the GPU; there is no CPU path")
     return torch.cat(results, dim=2).squeeze(0)[:, :audio_length]
+
+
+# ------------------------------------------------------------------------------------------------
+# Encoder hand-off (remainder): hallo/utils/util.py:297-322 `tensor_to_video` wraps the uint8 frames in a
+# moviepy VideoClip, attaches the driving audio (cut to the video's duration) and writes H.264 + AAC through ffmpeg.  moviepy
+# is a frame pump around an ffmpeg subprocess; here the bytes that hallo_frames_to_uint8 produced go to the same subprocess
+# directly.  No encoder ships with this package: without an `ffmpeg` binary the call fails loudly, and `write_raw_rgb24` is
+# the encoder-agnostic hand-off (raw frames + a JSON sidecar any muxer can be pointed at).
+# ------------------------------------------------------------------------------------------------
+def ffmpeg_command(ffmpeg, width, height, fps, n_frames, output_video_file, audio_source=None):
+    """The ffmpeg invocation that reproduces moviepy's `write_videofile(path, fps=fps, audio_codec="aac")` defaults (libx264,
+    yuv420p, medium preset) for raw RGB24 frames arriving on stdin; the audio is cut to the video's duration
+    (`AudioFileClip(audio_source).subclip(0, n_frames / fps)`, util.py:319-320)."""
+    cmd = [ffmpeg, "-y", "-loglevel", "error", "-f", "rawvideo", "-vcodec", "rawvideo", "-s", f"{width}x{height}", "-pix_fmt", "rgb24",
+           "-r", f"{fps}", "-i", "-"]
+    if audio_source is not None:
+        cmd += ["-t", f"{n_frames / fps:.6f}", "-i", str(audio_source), "-c:a", "aac"]
+    else:
+        cmd += ["-an"]
+    cmd += ["-c:v", "libx264", "-preset", "medium", "-pix_fmt", "yuv420p", "-r", f"{fps}", "-frames:v", str(n_frames), str(output_video_file)]
+    return cmd
+
+
+def tensor_to_video(frames, output_video_file, audio_source=None, fps=25, ffmpeg=None):
+    """hallo/utils/util.py:297-322.  `frames`: uint8 (F, H, W, 3) as generate_video(output="uint8") returns them, or the
+    reference's fp32 tensor (3, F, H, W) in [0, 1] (converted with the reference's clip-and-truncate rule; device tensors through
+    hallo_frames_to_uint8).  Streams the frames to an ffmpeg subprocess; raises if no ffmpeg binary is available."""
+    import shutil
+    import subprocess
+    if frames.dtype != torch.uint8:
+        if frames.is_cuda:
+            frames = frames_to_uint8(frames.float())
+        else:
+            frames = (frames.float().permute(1, 2, 3, 0) * 255).clamp_(0, 255).to(torch.uint8)      # np.clip(x * 255, 0, 255).astype(uint8)
+    frames = frames.cpu().contiguous()
+    Fr, H, W, Cc = frames.shape
+    if Cc != 3:
+        raise ValueError("tensor_to_video expects RGB frames (F, H, W, 3)")
+    exe = ffmpeg or shutil.which("ffmpeg")
+    if exe is None:
+        raise RuntimeError("no ffmpeg binary on PATH: hallo_amd ships no encoder; use write_raw_rgb24() and mux elsewhere")
+    cmd = ffmpeg_command(exe, W, H, fps, Fr, output_video_file, audio_source)
+    proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, stderr=subprocess.PIPE)
+    _, err = proc.communicate(frames.numpy().tobytes())
+    if proc.returncode != 0:
+        raise RuntimeError(f"ffmpeg failed ({proc.returncode}): {err.decode(errors='replace')[-500:]}")
+    return output_video_file
+
+
+def write_raw_rgb24(frames, path, fps=25):
+    """Encoder-agnostic hand-off: uint8 (F, H, W, 3) frames as one raw RGB24 file + `<path>.json` (width, height, fps, frames,
+    pix_fmt) -- `ffmpeg -f rawvideo -pix_fmt rgb24 -s WxH -r fps -i path ...` or any other muxer picks it up."""
+    import json
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+        raise ValueError("write_raw_rgb24 expects uint8 frames (F, H, W, 3)")
+    frames = frames.cpu().contiguous()
+    with open(path, "wb") as f:
+        f.write(frames.numpy().tobytes())
+    meta = {"width": int(frames.shape[2]), "height": int(frames.shape[1]), "fps": fps, "frames": int(frames.shape[0]), "pix_fmt": "rgb24"}
+    with open(str(path) + ".json", "w") as f:
+        json.dump(meta, f)
+    return meta

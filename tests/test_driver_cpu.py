@@ -113,3 +113,51 @@ def test_uint8_output_needs_the_gpu_kernel():
     with pytest.raises(HalloLibraryError):
         V.generate_video(_FakePipe(), lambda a: a.flatten(2)[:, :, None, :], src, region, emb, fm, cm, lm, audio,
                          clip_length=16, img_size=(16, 16), inference_steps=1, output="uint8")
+
+
+def test_tensor_to_video_hands_the_reference_bytes_to_the_encoder(tmp_path):
+    """SURVEY 8f row 3 (hallo/utils/util.py:297-322): the uint8 frames go to an ffmpeg subprocess as raw RGB24 with the
+    reference's container settings (fps, libx264 / aac, audio cut to the video's duration).  A stand-in `ffmpeg` script records
+    its arguments and stdin: the bytes must be exactly the reference's `np.clip(x * 255, 0, 255).astype(np.uint8)` frames."""
+    import json
+    import os
+    import stat
+    import numpy as np
+    import pytest
+    import torch
+    from hallo_amd.animate import video as V
+    fake = tmp_path / "ffmpeg"
+    fake.write_text("#!/bin/sh\nprintf '%s\\n' \"$@\" > \"$0.args\"\ncat > \"$0.stdin\"\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    g = torch.Generator().manual_seed(5)
+    vid = torch.rand((3, 7, 16, 24), generator=g) * 1.2 - 0.1                     # the reference's (c, f, h, w) tensor, slightly out of range
+    out = tmp_path / "out.mp4"
+    V.tensor_to_video(vid, out, audio_source="speech.wav", fps=25, ffmpeg=str(fake))
+    want = np.clip(vid.permute(1, 2, 3, 0).numpy() * 255, 0, 255).astype(np.uint8)   # util.py:308-312
+    got = np.frombuffer(open(str(fake) + ".stdin", "rb").read(), dtype=np.uint8).reshape(want.shape)
+    assert np.array_equal(got, want)
+    args = open(str(fake) + ".args").read().split("\n")
+    for token in ("rawvideo", "24x16", "rgb24", "25", "speech.wav", "aac", "libx264", "yuv420p", str(out)):
+        assert token in args, token
+    assert args[args.index("-t") + 1] == f"{7 / 25:.6f}"                            # AudioFileClip(...).subclip(0, frames / fps)
+    # uint8 frames (what generate_video(output="uint8") returns) pass through untouched; no audio -> -an
+    V.tensor_to_video(torch.from_numpy(want.copy()), out, fps=30, ffmpeg=str(fake))
+    assert np.array_equal(np.frombuffer(open(str(fake) + ".stdin", "rb").read(), dtype=np.uint8).reshape(want.shape), want)
+    assert "-an" in open(str(fake) + ".args").read().split("\n")
+    # a failing encoder and a missing one are loud
+    bad = tmp_path / "ffmpeg_bad"
+    bad.write_text("#!/bin/sh\ncat > /dev/null\necho boom >&2\nexit 3\n")
+    bad.chmod(bad.stat().st_mode | stat.S_IEXEC)
+    with pytest.raises(RuntimeError, match="boom"):
+        V.tensor_to_video(vid, out, ffmpeg=str(bad))
+    old = os.environ.get("PATH", "")
+    os.environ["PATH"] = str(tmp_path / "nowhere")
+    try:
+        with pytest.raises(RuntimeError, match="no ffmpeg"):
+            V.tensor_to_video(vid, out)
+    finally:
+        os.environ["PATH"] = old
+    meta = V.write_raw_rgb24(torch.from_numpy(want.copy()), tmp_path / "frames.rgb", fps=25)
+    assert meta == {"width": 24, "height": 16, "fps": 25, "frames": 7, "pix_fmt": "rgb24"}
+    assert json.load(open(str(tmp_path / "frames.rgb") + ".json")) == meta
+    assert os.path.getsize(tmp_path / "frames.rgb") == want.size
