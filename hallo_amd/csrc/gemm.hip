@@ -855,6 +855,12 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
           else if (nk >= 20 && t128 >= 224 && t128 <= 256) { tm = 1; sp = 1; }
         } else if (!conv && nk >= 20) {
           if (fills(t256)) { tm = 2; sp = 1; }
+          else if (nk >= 40 && batch == 1 && !a.out_f32 && a.tiles_m * a.tiles_n < 384) {
+            // long-K projections of the 16x16 / 8x8 levels (ff.net[2] at K = 2560 / 5120), where the 128x128 kernel would split K
+            // as well: cold, the split big tile wins by 7-10 us (profiles/r3_gemm_cold_bench.json: 77 vs 87, 38 vs 46, 40 vs 48 us)
+            if (sp256 > 1 && fills(t256 * sp256) && nk / sp256 >= 20) { tm = 2; sp = sp256; }
+            else if (sp128 > 1 && fills(t128 * sp128) && nk / sp128 >= 5) { tm = 1; sp = sp128; }
+          }
         }
       }
     }

@@ -622,10 +622,13 @@ def test_cfg_ddim_step_modes(pred, clip, report):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,HW,Cd,silu", [(16, 256, 1280, True), (4, 1024, 640, False), (16, 64, 2560, True), (8, 100, 1920, True),
-                                          (4, 256, 128, True), (2, 1024, 960, False)])
+                                          (4, 256, 128, True), (2, 1024, 960, False), (16, 4096, 320, True), (18, 4096, 320, False),
+                                          (3, 4096, 640, True), (2, 4096, 960, True), (5, 4000, 320, True), (16, 1024, 1280, True),
+                                          (16, 256, 2560, True), (16, 64, 1280, False), (2, 9216, 320, True)])
 def test_groupnorm_single_launch_path(dtype, n, HW, Cd, silu, report):
-    """Small feature maps take the one-launch kernel (channel slices of whole groups); it must agree with the fp32
-    expression and -- both being deterministic -- be selected purely by shape (gn_fused switch for the A/B)."""
+    """Small feature maps take the one-launch kernel (channel slices of whole groups), larger ones the statistics + apply
+    launch pair; both must agree with the fp32 expression and -- both being deterministic -- be selected purely by shape
+    (gn_fused switch for the A/B)."""
     from hallo_amd import ops
     from oracle import ops_ref
     g = torch.Generator().manual_seed(n + HW + Cd)
@@ -634,6 +637,7 @@ def test_groupnorm_single_launch_path(dtype, n, HW, Cd, silu, report):
     out = ops.groupnorm(x, gm, bt, n, HW, 32, 1e-5, silu=silu)
     ref = ops_ref.groupnorm_nhwc(x, gm, bt, 32, 1e-5, silu=silu)
     _check(f"groupnorm_fused[{n},{HW},{Cd}]", out, ref, dtype, report)
+    assert torch.equal(out, ops.groupnorm(x, gm, bt, n, HW, 32, 1e-5, silu=silu)), "not bit-reproducible"
     ops.set_option("gn_fused", 0)
     try:
         two = ops.groupnorm(x, gm, bt, n, HW, 32, 1e-5, silu=silu)

@@ -359,6 +359,9 @@ def test_gemm_rs2_cfg_and_768_row_counts(dtype, M, kind, report):
     (32768, 640, 2560, "res"),        # configs[2] L1 ff.net[2]
     (55296, 2560, 640, "geglu-ln"),   # configs[4] L1 GEGLU with the LayerNorm epilogue (24 x 48 x 48 rows)
     (147456, 320, 320, "res"),        # configs[2] motion-module to_out + residual
+    (4096, 1280, 5120, "res-splitk"),     # configs[1] 16 x 16 level ff.net[2]: 256-row big tile, K split 4 ways (64 tiles -> 256 workgroups)
+    (4096, 640, 2560, "res-splitk"),      # 128-row big tile, K split 4 ways
+    (1024, 1280, 5120, "res-splitk"),     # 8 x 8 level: 128-row big tile, K split 8 ways
 ])
 def test_gemm_big_tile_cfg_and_768_row_counts(dtype, M, N, K, kind, report):
     from hallo_amd import ops
@@ -382,6 +385,10 @@ def test_gemm_big_tile_cfg_and_768_row_counts(dtype, M, N, K, kind, report):
         res = _rand((M, N), dtype, g)
         out = ops.gemm(a, w, b, residual=res)
         ref = ops_ref.linear(a, w, b) + res.float()
+        if kind == "res-splitk":
+            # the long-K rule of launch_gemm (csrc/gemm.hip): gemm3_kernel + fp32 slabs + the fixed-order reduce pass
+            assert (ops.get_option("last_gemm_kernel") // 100) % 10 == 3, ops.get_option("last_gemm_kernel")
+            assert torch.equal(out, ops.gemm(a, w, b, residual=res)), "split-K result is not bit-reproducible"
     _check(f"gemm_rows[{M},{N},{K},{kind}]", out, ref, dtype, report)
 
 

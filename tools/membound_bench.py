@@ -55,17 +55,19 @@ by = xs[0].numel() * 2
 report("reference: torch copy_ (read + write)", timeit(lambda i: ys[i].copy_(xs[i]), SETS), 2 * by)
 report("reference: torch sum (read only)", timeit(lambda i: xs[i].sum(), SETS), by)
 gamma, beta = rnd(C), rnd(C)
-report("groupnorm+silu L0 (16,4096,320): stats + apply", timeit(lambda i: ops.groupnorm(xs[i], gamma, beta, n, L, 32, 1e-5, silu=True, out=ys[i]), SETS), 3 * by,
-       "2 reads + 1 write")
-x1 = [rnd(16, 1024, 640) for _ in range(SETS)]
-y1 = [torch.empty_like(x) for x in x1]
-g1, b1 = rnd(640), rnd(640)
-report("groupnorm+silu L1 (16,1024,640): single launch", timeit(lambda i: ops.groupnorm(x1[i], g1, b1, 16, 1024, 32, 1e-5, silu=True, out=y1[i]), SETS), 2 * x1[0].numel() * 2,
-       "1 HBM read (+ L2 re-read) + 1 write")
-x2 = [rnd(16, 256, 1280) for _ in range(SETS)]
-y2 = [torch.empty_like(x) for x in x2]
-g2, b2 = rnd(1280), rnd(1280)
-report("groupnorm+silu L2 (16,256,1280): single launch", timeit(lambda i: ops.groupnorm(x2[i], g2, b2, 16, 256, 32, 1e-5, silu=True, out=y2[i]), SETS), 2 * x2[0].numel() * 2)
+GN_FORMS = {1: "single launch, slice re-read from L2", 0: "statistics + apply launches"}
+for (gn, gL, gC) in [(16, 4096, 320), (16, 4096, 640), (16, 1024, 640), (16, 1024, 1280), (16, 256, 1280), (16, 256, 2560), (16, 64, 1280), (16, 64, 2560)]:
+    gx = [rnd(gn, gL, gC) for _ in range(SETS)] if (gL, gC) != (L, C) else xs
+    gy = [torch.empty_like(t) for t in gx]
+    gg, gb = rnd(gC), rnd(gC)
+    for form in (1, 0):
+        if form == 1 and gL > 1024:
+            continue
+        ops.set_option("gn_fused", form)
+        report(f"groupnorm+silu ({gn},{gL},{gC}): {GN_FORMS[form]}",
+               timeit(lambda i: ops.groupnorm(gx[i], gg, gb, gn, gL, 32, 1e-5, silu=True, out=gy[i]), SETS), 2 * gx[0].numel() * 2, "1 read + 1 write counted")
+    ops.set_option("gn_fused", 1)
+    del gx, gy
 # concat copy: [n*L, 320] + [n*L, 320] -> [n*L, 640]
 cat = [torch.empty((n * L, 2 * C), device=dev, dtype=dt) for _ in range(SETS)]
 report("copy2d concat half (65536 x 320 -> ld 640)", timeit(lambda i: ops.copy2d(xs[i].view(n * L, C), cat[i], n * L, C), SETS), 2 * by)
