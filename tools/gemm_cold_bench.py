@@ -26,8 +26,8 @@ SHAPES = [      # M, N, K, residual, geglu  (launch counts per 25-step clip in p
     (1024, 1280, 5120, True, False), (65536, 320, 1280, True, False), (65536, 320, 320, True, False),
     (16384, 2560, 640, False, True), (4096, 5120, 1280, False, True), (65536, 1280, 320, False, True),
 ]
-if os.environ.get("GC_SHAPES"):
-    SHAPES = [SHAPES[int(i)] for i in os.environ["GC_SHAPES"].split(",")]
+if os.environ.get("GC_SHAPES") is not None:
+    SHAPES = [SHAPES[int(i)] for i in os.environ["GC_SHAPES"].split(",") if i != ""]
 
 
 def timeit(fn_of_set, nsets, min_ms=60.0):
@@ -86,6 +86,42 @@ for (M, N, K, res, geglu) in SHAPES:
         print(rec, flush=True)
     ops.set_option("gemm_variant", 6)
     del A, W, R, C
+    torch.cuda.empty_cache()
+
+# 3x3 convolutions (implicit GEMM) of the same levels: n_img, side, Cin, Cout, residual
+CONVS = [(16, 64, 320, 320, True), (16, 64, 640, 320, False), (16, 64, 960, 320, False), (16, 32, 640, 640, True), (16, 32, 640, 640, False),
+         (16, 32, 1280, 640, False), (16, 32, 1920, 640, False), (16, 16, 1280, 1280, True), (16, 16, 1280, 1280, False),
+         (16, 16, 2560, 1280, False), (16, 8, 1280, 1280, True), (16, 8, 2560, 1280, False)]
+if os.environ.get("GC_CONVS") is not None:
+    CONVS = [CONVS[int(i)] for i in os.environ["GC_CONVS"].split(",") if i != ""]
+for (n, side, Ci, Co, res) in CONVS:
+    L = side * side
+    per_set = 2 * (n * L * Ci + Co * 9 * Ci + n * L * Co * (2 if res else 1))
+    nsets = max(2, min(64, -(-COLD_BYTES // per_set)))
+    X = [torch.randn((n, L, Ci), device=dev).to(dt) for _ in range(nsets)]
+    Wc = [(torch.randn((Co, 9 * Ci), device=dev) * (9 * Ci) ** -0.5).to(dt) for _ in range(nsets)]
+    R = [torch.randn((n, L, Co), device=dev).to(dt) for _ in range(nsets)] if res else None
+    Y = [torch.empty((n, L, Co), device=dev, dtype=dt) for _ in range(nsets)]
+    bias = torch.randn((Co,), device=dev).to(dt)
+    flop = 2.0 * n * L * Co * 9 * Ci
+    ref = None
+    for v in VARIANTS:
+        ops.set_option("gemm_variant", v)
+        f = lambda i: ops.conv3x3(X[i], Wc[i], bias, n, side, side, residual=R[i] if res else None, out=Y[i])
+        f(0)
+        kern = ops.get_option("last_gemm_kernel")
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = Y[0].float().clone()
+        err = float((Y[0].float() - ref).norm() / ref.norm())
+        cold = timeit(f, nsets)
+        hot = timeit(lambda i: f(0), 1)
+        rec = dict(conv=[n, side, Ci, Co], res=res, variant=v, kernel=kern, sets=nsets, cold_us=round(cold, 1), hot_us=round(hot, 1),
+                   cold_tflops=round(flop / cold / 1e6, 1), hot_tflops=round(flop / hot / 1e6, 1), rel_vs_first=round(err, 6))
+        out.append(rec)
+        print(rec, flush=True)
+    ops.set_option("gemm_variant", 6)
+    del X, Wc, R, Y
     torch.cuda.empty_cache()
 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
