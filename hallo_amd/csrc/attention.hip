@@ -709,10 +709,13 @@ extern "C" int hallo_get_option_attn(const char* name) {
   return -22;
 }
 
+extern "C" int hallo_set_option_xattn(const char* name, int value);
+
 extern "C" int hallo_set_option_attn(const char* name, int value) {
   if (name && !strcmp(name, "temporal_mfma")) { if (value < 0 || value > 1) return -22; g_temporal_mfma = value; return 0; }
   if (name && !strcmp(name, "attn_order")) { if (value < 0 || value > 2) return -22; g_attn_order = value; return 0; }
   if (name && !strcmp(name, "attn40")) { if (value < 0 || value > 8) return -22; g_attn40 = value; set_attn40_variant(value); return 0; }
+  if (name && !strcmp(name, "xattn_tiled")) return hallo_set_option_xattn(name, value);     // fused_xattn.hip
   return -22;
 }
 

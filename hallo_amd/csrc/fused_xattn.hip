@@ -21,6 +21,7 @@
 // that matches the accumulator layout of the first contraction).
 #include "common.h"
 #include "../../include/hallo_amd.h"
+#include <string.h>
 
 namespace hallo {
 
@@ -133,9 +134,177 @@ __global__ __launch_bounds__(256) void face_xattn_kernel(const XattnArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 3: the same operator for C = 320 / 640 / 1280 with the activations staged through LDS.
+//
+// The kernel above reads x in the MFMA operand form: a lane owns a ROW and fetches 16 bytes of it per k slice, so one wave
+// instruction touches 32 rows x 32 bytes -- 32 partial cache lines -- and the output leaves in 8-byte pieces at a row stride
+// (the write pattern that cost attention40 1.4x its output bytes before its epilogue was changed).  Timed cold it moves 84 MB in
+// 51 us at C = 320 (1.6 TB/s, a device copy does the same bytes in 18) and 21 MB in 37 us at C = 1280.
+//
+// Here a workgroup walks 32-row blocks (persistent: blocks b, b + grid, ...).  Per block:
+//   1. x[32][C] -> LDS by 16-byte loads, consecutive lanes = consecutive 16-byte pieces of a row (whole 128-byte lines), rows at
+//      a pitch of 2C + 16 bytes (the 16 rows of a ds_read_b128 lane group fall on 16 distinct 16-byte bank groups);
+//   2. scores^T = Sg . X^T with X fragments from LDS; Sg (and further down OwP) fragments live in REGISTERS for the whole kernel
+//      -- their row-per-lane loads are issued once per workgroup, not once per 32 rows;
+//   3. softmax as above; O^T = OwP . P^T + bias + residual (the residual comes from the LDS tile), written back INTO the tile;
+//   4. tile -> y by 16-byte stores of whole lines.
+// k slices and channel blocks are dealt to the 4 waves exactly as above and partial sums are combined in the same order, so the
+// two kernels agree bit for bit (tests/test_ops_gpu.py compares them).
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename T, int C>
+__global__ __launch_bounds__(256) void face_xattn_tiled_kernel(const XattnArgs p, int nblocks) {
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  constexpr int PITCH = C * 2 + 16;              // bytes
+  constexpr int NKS = C / 16, NKW = NKS / 4;     // k slices, per wave (C / 64: 5, 10, 20)
+  constexpr int NCB = C / 32, NCW = (NCB + 3) / 4;
+  constexpr int CPR = C / 8;                     // 16-byte pieces per row
+  constexpr int NLD = 32 * CPR / 256;            // pieces per thread (C / 64)
+  static_assert(NKS % 4 == 0 && (32 * CPR) % 256 == 0, "C must be a multiple of 64");
+  __shared__ __attribute__((aligned(16))) unsigned char tile[32 * PITCH];
+  __shared__ float s_part[4][16][64];
+  __shared__ float s_stat[4][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const T* __restrict__ bo = reinterpret_cast<const T*>(p.bo);
+  const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+
+  V8 sgf[NKW];               // Sg[(h,t) = l31][ks * 16 + hi * 8 ..], ks = wave + 4 j
+  V8 ow0[NCW], ow1[NCW];     // OwP[c = cb * 32 + l31][hi * 8 ..] and [16 + hi * 8 ..], cb = wave + 4 j
+  float gv[4][4], bv[4][4];
+  long cur_b = -1;
+
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const long row0 = (long)blk * 32;
+    const long bidx = row0 / p.rows_per_batch;                 // block-uniform: rows_per_batch % 32 == 0
+    if (bidx != cur_b) {                                       // (re)load the per-batch constants: once per workgroup unless it crosses batches
+      cur_b = bidx;
+      const T* sg = reinterpret_cast<const T*>(p.sg) + (bidx * 32 + l31) * C;
+      const T* owp = reinterpret_cast<const T*>(p.owp) + bidx * C * 32;
+#pragma unroll
+      for (int j = 0; j < NKW; ++j) sgf[j] = ld8<T>(sg + (wave + 4 * j) * 16 + hi * 8);
+#pragma unroll
+      for (int j = 0; j < NCW; ++j) {
+        const int cb = wave + 4 * j;
+        if (cb < NCB) {
+          const T* wrow = owp + (long)(cb * 32 + l31) * 32 + hi * 8;
+          ow0[j] = ld8<T>(wrow);
+          ow1[j] = ld8<T>(wrow + 16);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          gv[g][jj] = p.g[bidx * 32 + 8 * g + 4 * hi + jj];
+          bv[g][jj] = p.b[bidx * 32 + 8 * g + 4 * hi + jj];
+        }
+    }
+
+    // ---- 1. x block -> LDS ----
+    {
+      const T* xb = reinterpret_cast<const T*>(p.x);
+      V8 st[NLD];
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int q = tid + 256 * i, r = q / CPR, cc = q - r * CPR;
+        st[i] = ld8<T>(xb + min(row0 + r, p.rows - 1) * C + cc * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int q = tid + 256 * i, r = q / CPR, cc = q - r * CPR;
+        *reinterpret_cast<V8*>(tile + r * PITCH + cc * 16) = st[i];
+      }
+    }
+    __syncthreads();
+
+    // ---- 2. partial scores^T and row statistics over this wave's k slices ----
+    f32x16 s = zero16;
+    float sum = 0.0f, sq = 0.0f;
+    const unsigned char* xrow = tile + l31 * PITCH;
+#pragma unroll
+    for (int j = 0; j < NKW; ++j) {
+      const V8 xf = *reinterpret_cast<const V8*>(xrow + ((wave + 4 * j) * 16 + hi * 8) * 2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float f = to_f32(xf[e]); sum += f; sq = __builtin_fmaf(f, f, sq); }
+      s = Vec<T>::mfma32(sgf[j], xf, s);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_part[wave][r][lane] = s[r];
+    s_stat[wave][0][lane] = sum;
+    s_stat[wave][1][lane] = sq;
+    __syncthreads();
+    sum = (s_stat[0][0][lane] + s_stat[1][0][lane]) + (s_stat[2][0][lane] + s_stat[3][0][lane]);
+    sq = (s_stat[0][1][lane] + s_stat[1][1][lane]) + (s_stat[2][1][lane] + s_stat[3][1][lane]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = (s_part[0][r][lane] + s_part[1][r][lane]) + (s_part[2][r][lane] + s_part[3][r][lane]);
+    sum += __shfl_xor(sum, 32, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    const float mean = sum / (float)C;
+    const float var = fmaxf(sq / (float)C - mean * mean, 0.0f);
+    const float rstd = rsqrtf(var + p.eps);
+
+    // ---- 3. softmax over the 4 tokens of each head; O^T blocks + bias + residual, back into the tile ----
+    V8 pf[2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float sc[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) sc[jj] = __builtin_fmaf(rstd, s[4 * g + jj] - mean * gv[g][jj], bv[g][jj]);
+      const float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+      float e4[4], l = 0.0f;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) { e4[jj] = __builtin_amdgcn_exp2f(sc[jj] - m); l += e4[jj]; }
+      const float inv = __builtin_amdgcn_rcpf(l);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) pf[g >> 1][(g & 1) * 4 + jj] = from_f32<T>(e4[jj] * inv);
+    }
+    unsigned char* yrow = tile + l31 * PITCH;
+#pragma unroll
+    for (int j = 0; j < NCW; ++j) {
+      const int cb = wave + 4 * j;
+      if (cb < NCB) {
+        f32x16 o = Vec<T>::mfma32(ow0[j], pf[0], zero16);
+        o = Vec<T>::mfma32(ow1[j], pf[1], o);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = cb * 32 + 8 * g + 4 * hi;
+          const V4 res = *reinterpret_cast<const V4*>(yrow + c * 2);
+          const V4 bb = *reinterpret_cast<const V4*>(bo + c);
+          V4 out;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) out[jj] = from_f32<T>(o[4 * g + jj] + to_f32(bb[jj]) + to_f32(res[jj]));
+          *reinterpret_cast<V4*>(yrow + c * 2) = out;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- 4. tile -> y ----
+    {
+      T* yb = reinterpret_cast<T*>(p.y);
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int q = tid + 256 * i, r = q / CPR, cc = q - r * CPR;
+        const V8 v = *reinterpret_cast<const V8*>(tile + r * PITCH + cc * 16);
+        if (row0 + r < p.rows) st8<T>(yb + (row0 + r) * C + cc * 8, v);
+      }
+    }
+    __syncthreads();       // the next block's loads overwrite the tile
+  }
+}
+
 }  // namespace hallo
 
 using namespace hallo;
+
+static int g_xattn_tiled = 1;    // hallo_set_option("xattn_tiled", 0 | 1): LDS-staged face cross-attention for C = 320 / 640 / 1280 (A/B)
+extern "C" int hallo_set_option_xattn(const char* name, int value) {
+  if (name && !strcmp(name, "xattn_tiled")) { if (value < 0 || value > 1) return -22; g_xattn_tiled = value; return 0; }
+  return -2;
+}
 
 extern "C" int hallo_face_xattn(const void* x, void* y, const void* sg, const float* g, const float* b, const void* owp,
                                 const void* bo, int64_t rows, int C, int64_t rows_per_batch, float eps, int dtype,
@@ -147,6 +316,17 @@ extern "C" int hallo_face_xattn(const void* x, void* y, const void* sg, const fl
   a.rows = rows; a.C = C; a.rows_per_batch = rows_per_batch; a.eps = eps;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((unsigned)((rows + 31) / 32)), block(256);
+  if (g_xattn_tiled && (C == 320 || C == 640 || C == 1280) && (dtype == DT_F16 || dtype == DT_BF16)) {
+    // persistent: <= 2 workgroups per CU in flight walk the 32-row blocks (the per-batch constants load once per workgroup)
+    const int nblocks = (int)grid.x;
+    const dim3 pg((unsigned)(nblocks < 512 ? nblocks : 512));
+#define HALLO_XT(TT, CC) hipLaunchKernelGGL((face_xattn_tiled_kernel<TT, CC>), pg, block, 0, st, a, nblocks)
+    if (dtype == DT_F16) { if (C == 320) HALLO_XT(_Float16, 320); else if (C == 640) HALLO_XT(_Float16, 640); else HALLO_XT(_Float16, 1280); }
+    else { if (C == 320) HALLO_XT(__bf16, 320); else if (C == 640) HALLO_XT(__bf16, 640); else HALLO_XT(__bf16, 1280); }
+#undef HALLO_XT
+    HALLO_CHECK_LAUNCH();
+    return 0;
+  }
   if (dtype == DT_F16) hipLaunchKernelGGL((face_xattn_kernel<_Float16>), grid, block, 0, st, a);
   else if (dtype == DT_BF16) hipLaunchKernelGGL((face_xattn_kernel<__bf16>), grid, block, 0, st, a);
   else return -22;

@@ -424,7 +424,8 @@ def test_attention_prescaled_q(dtype, hd, Lq, Lkv, report):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("Cd,heads,rows_pb,nb", [(320, 8, 256, 2), (640, 8, 96, 1), (1280, 8, 64, 2), (160, 2, 128, 2)])
+@pytest.mark.parametrize("Cd,heads,rows_pb,nb", [(320, 8, 256, 2), (640, 8, 96, 1), (1280, 8, 64, 2), (160, 2, 128, 2), (320, 8, 32 * 700, 2),
+                                                 (320, 5, 96, 3), (640, 8, 32 * 300, 2), (1280, 8, 32 * 300, 2)])
 def test_face_xattn_fused(dtype, Cd, heads, rows_pb, nb, report):
     """hallo_face_xattn vs the unfused chain LayerNorm -> to_q -> SDPA(4 face tokens) -> to_out + residual in fp32
     (mutual_self_attention.py:286-303).  heads < 8 exercises the zero-padded (head, token) slots; the last case has
@@ -452,6 +453,12 @@ def test_face_xattn_fused(dtype, Cd, heads, rows_pb, nb, report):
     y = x.clone()
     ops.face_xattn(y, sg, gg, bb, owp, bo, rows_pb, 1e-5, out=y)          # in place
     assert torch.equal(y, out)
+    # C = 320 / 640 / 1280 run the LDS-staged kernel; the row-per-lane kernel (any C) must give the same bits
+    ops.set_option("xattn_tiled", 0)
+    try:
+        assert torch.equal(ops.face_xattn(x, sg, gg, bb, owp, bo, rows_pb, 1e-5), out)
+    finally:
+        ops.set_option("xattn_tiled", 1)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -90,6 +90,22 @@ kv3 = rnd(16, 32, 1920)
 o3 = [torch.empty_like(q) for q in q3]
 report("token cross-attention (16,4096,960) x 32 tokens", timeit(lambda i: ops.attention(q3[i], kv3[:, :, :960], kv3[:, :, 960:], 24, out=o3[i], q_prescaled=True), SETS),
        2 * q3[0].numel() * 2)
+# fused face cross-attention (norm2 + attn2 + residual): row-per-lane kernel vs the LDS-staged one
+for (fr, fC) in [(65536, 320), (73728, 320), (16384, 640), (4096, 1280)]:
+    fx = [rnd(fr, fC) for _ in range(SETS)]
+    fy = [torch.empty_like(t) for t in fx]
+    fwq, fwo = rnd(fC, fC) * fC ** -0.5, rnd(fC, fC) * fC ** -0.5
+    fkf, fvf = rnd(1, 4, fC), rnd(1, 4, fC)
+    fsg, fgg, fbb, fowp = ops.face_xattn_constants(fwq, fkf, fvf, fwo, 1.0 + 0.1 * rnd(fC), 0.1 * rnd(fC), 8, dt)
+    fbo = rnd(fC)
+    res = {}
+    for tiled in (0, 1):
+        ops.set_option("xattn_tiled", tiled)
+        us = timeit(lambda i: ops.face_xattn(fx[i], fsg, fgg, fbb, fowp, fbo, fr, 1e-5, out=fy[i]), SETS)
+        res[tiled] = fy[0].clone()
+        report(f"face cross-attention ({fr}, {fC}): {'LDS-staged' if tiled else 'row per lane'}", us, 2 * fx[0].numel() * 2, "x read, y written")
+    print("   identical:", torch.equal(res[0], res[1]), flush=True)
+    del fx, fy
 # fused qkv with LayerNorm (row-stationary), output-stream bound
 wq = rnd(960, C) * C ** -0.5
 wf, cs, bf = ops.fold_layernorm(gamma, beta, wq, rnd(960))
