@@ -65,7 +65,8 @@ for (gn, gL, gC) in [(16, 4096, 320), (16, 4096, 640), (16, 1024, 640), (16, 102
             continue
         ops.set_option("gn_fused", form)
         report(f"groupnorm+silu ({gn},{gL},{gC}): {GN_FORMS[form]}",
-               timeit(lambda i: ops.groupnorm(gx[i], gg, gb, gn, gL, 32, 1e-5, silu=True, out=gy[i]), SETS), 2 * gx[0].numel() * 2, "1 read + 1 write counted")
+               timeit(lambda i: ops.groupnorm(gx[i], gg, gb, gn, gL, 32, 1e-5, silu=True, out=gy[i]), SETS), (3 if form == 0 else 2) * gx[0].numel() * 2,
+               "2 reads + 1 write" if form == 0 else "1 HBM read (+ L2 re-read) + 1 write")
     ops.set_option("gn_fused", 1)
     del gx, gy
 # concat copy: [n*L, 320] + [n*L, 320] -> [n*L, 640]
