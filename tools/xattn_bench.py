@@ -30,9 +30,22 @@ for dtype in (torch.bfloat16, torch.float16):
                 ts.append(s.elapsed_time(e) / 20)
             res[order] = (sorted(ts)[len(ts) // 2], o.float().clone())
         ops.set_option("attn_order", 2)
+        t_generic = None
+        if Cq // heads == 40:            # hd 40: attention40.hip (64-key tiles, LDS constants per workgroup) vs the generic kernel of attention.hip
+            ops.set_option("attn40", 0)
+            for _ in range(5): run()
+            ts = []
+            for _ in range(7):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(20): run()
+                e.record(); torch.cuda.synchronize()
+                ts.append(s.elapsed_time(e) / 20)
+            t_generic = round(sorted(ts)[len(ts) // 2] * 1e3, 1)
+            ops.set_option("attn40", 1)
         by = 2 * 2 * q.numel()
         same = torch.equal(res[0][1], res[2][1])
         rec = dict(shape=name, dtype=str(dtype), us_qblock_fastest=round(res[0][0] * 1e3, 1), us_head_fastest=round(res[2][0] * 1e3, 1),
-                   gbs=round(by / res[2][0] / 1e6, 1), hbm_frac=round(by / res[2][0] / 1e6 / 8000, 3), identical_output=same)
+                   gbs=round(by / res[2][0] / 1e6, 1), hbm_frac=round(by / res[2][0] / 1e6 / 8000, 3), identical_output=same, us_generic_kernel=t_generic)
         out.append(rec); print(rec, flush=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "xattn_bench.json"), "w"), indent=1)
