@@ -77,7 +77,10 @@ class OpProfiler:
             return "gemm3_kernel<%s,%d,%d,%s>" % (dt, mode, sub & 3, "true" if sub & 4 else "false")
         if name == "attention":
             hd = a[0].shape[-1] // a[3]
-            if hd == 40 and k.get("q_prescaled") and ops.get_option("attn40") > 0:
+            which = ops.get_option("last_attn_kernel")        # asked from the library: 1 flash kernel, 2 attention40.hip, 3 token kernel
+            if which == 3:
+                return "tok_attn_kernel<%s,%d>" % (dt, hd)    # csrc/attention.hip: K/V of <= 32 rows, query tiles through LDS
+            if which == 2:
                 return "attn40_kernel<%s,16,0>" % dt          # csrc/attention40.hip (LDS-DMA K/V, transposing V reads)
             return "attn_kernel<%s,%d,%s>" % (dt, hd, "true" if k.get("q_prescaled") else "false")
         return name

@@ -659,6 +659,184 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const T* __rest
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// Token cross-attention (round 3): K/V of <= 32 rows -- the 32 audio tokens of a frame (hallo/models/attention.py:853-903,
+// the three masked branches x 8 heads as one launch) or the 4 face tokens on the unfused path -- against thousands of query
+// rows.  The flash kernels above give such a launch one workgroup per (query block, HEAD): a lane owns a query row and reads
+// 80 bytes of it, the output leaves the same way, and every workgroup pays the K/V staging and LDS set-up for 20 KB of
+// useful traffic: 81-95 us at the 64 x 64 level for 252 MB (a device copy moves them in 54).
+// Here the unit is a 32-row query tile x a GROUP of heads spanning 320 contiguous channels (8 heads at head dim 40, 4 at 80, 2 at 160):
+//   * workgroups are persistent over the tiles of one (frame, head group); the K fragments of a wave's heads stay in registers,
+//     their V rows in a wave-private LDS tile (row-major, read back transposed with ds_read_b64_tr_b16 as in the temporal kernel);
+//   * the query tile goes global -> LDS by whole-line 16-byte loads (pitch 2 CW + 16 B), S^T = K . Q^T takes its Q fragments from
+//     LDS, softmax over the <= 32 tokens is lane-local + one lane^32 exchange, O^T = V^T . P^T is scaled (1 / l, optional fp32 row
+//     scale) and written over the head's own Q columns of the tile, and the tile leaves by whole-line 16-byte stores.
+// q must be pre-scaled (head_dim^-1/2 * log2 e), as everything on the UNet path is.
+// -------------------------------------------------------------------------------------------
+template <typename T, int HD>
+__global__ __launch_bounds__(HD == 160 ? 128 : 256) void tok_attn_kernel(const AttnArgs p, int groups, int parts, int ntiles) {
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  constexpr int HG = (HD == 40) ? 8 : (HD == 80 ? 4 : 2);   // heads per workgroup: always 320 contiguous channels
+  constexpr int NT = (HD == 160) ? 128 : 256;        // threads: 4 waves x 2 heads, 4 x 1, 2 x 1
+  constexpr int HPW = HG / (NT / 64);                // heads per wave
+  constexpr int CW = HG * HD;                        // channels per workgroup: 320
+  constexpr int PITCH = CW * 2 + 16;                 // bytes
+  constexpr int HDP = ((HD + 15) / 16) * 16;
+  constexpr int NKS = HDP / 16, NDB = (HD + 31) / 32;
+  constexpr int VP = HDP * 2;                        // V tile row pitch in bytes (96 / 160 / 320)
+  constexpr int CPR = CW / 8, NLD = 32 * CPR / NT;
+  static_assert((32 * CPR) % NT == 0, "tile pieces per thread");
+  __shared__ __attribute__((aligned(16))) unsigned char tile[32 * PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned char vt_smem[(NT / 64) * HPW * 32 * VP];
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int bid = blockIdx.x;
+  const int part = bid % parts, hg = (bid / parts) % groups, b = bid / (parts * groups);
+  const int T_kv = p.Lkv1;
+  const T* __restrict__ Qg = reinterpret_cast<const T*>(p.q) + (long)b * p.q_bs + hg * CW;
+  T* __restrict__ Og = reinterpret_cast<T*>(p.o) + (long)b * p.o_bs + hg * CW;
+  const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+
+  // ---- once per workgroup: K fragments (lane = token) and the V tiles of this wave's heads ----
+  V8 kf[HPW][NKS];
+  lds_u8* const vt0 = (lds_u8*)vt_smem + wave * (HPW * 32 * VP);
+  {
+    const int tok = min(l31, T_kv - 1);
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+      const int h = hg * HG + wave * HPW + j;
+      const T* krow = reinterpret_cast<const T*>(p.k1) + (long)b * p.k1_bs + (long)tok * p.k1_rs + h * HD;
+      const T* vrow = reinterpret_cast<const T*>(p.v1) + (long)b * p.v1_bs + (long)tok * p.v1_rs + h * HD;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int d = ks * 16 + hi * 8;
+        kf[j][ks] = (d < HD) ? ld8<T>(krow + d) : zero8<T>();
+        const V8 v8 = (d < HD && l31 < T_kv) ? ld8<T>(vrow + d) : zero8<T>();        // rows >= T: zeros (their P is 0; 0 x garbage must not be NaN)
+        *(__attribute__((address_space(3))) V8*)(vt0 + j * (32 * VP) + l31 * VP + d * 2) = v8;
+      }
+    }
+  }
+  const int gi = lane & 15, gdh = (lane >> 4) & 1;
+
+  for (int t = part; t < ntiles; t += parts) {
+    const int row0 = t * 32;
+    // ---- query tile -> LDS ----
+    {
+      V8 st[NLD];
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int q = tid + NT * i, r = q / CPR, cc = q - r * CPR;
+        st[i] = ld8<T>(Qg + (long)min(row0 + r, p.Lq - 1) * p.q_rs + cc * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int q = tid + NT * i, r = q / CPR, cc = q - r * CPR;
+        *reinterpret_cast<V8*>(tile + r * PITCH + cc * 16) = st[i];
+      }
+    }
+    __syncthreads();
+    const int qrow = min(row0 + l31, p.Lq - 1);
+    unsigned char* trow = tile + l31 * PITCH;
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+      const int hc = wave * HPW + j, h = hg * HG + hc, col0 = hc * HD;
+      // S^T = K . Q^T (lane: query row l31, tokens 8g + 4hi + jj)
+      f32x16 s = zero16;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int d = ks * 16 + hi * 8;
+        const V8 xf = (d < HD) ? *reinterpret_cast<const V8*>(trow + (col0 + d) * 2) : zero8<T>();
+        s = Vec<T>::mfma32(kf[j][ks], xf, s);
+      }
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tk = 8 * (r >> 2) + 4 * hi + (r & 3);
+        s[r] = (tk < T_kv) ? s[r] : -3.0e38f;
+        mx = fmaxf(mx, s[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float l = 0.0f;
+      V8 pf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(s[r] - mx);
+        l += pv;
+        pf[r >> 3][r & 7] = from_f32<T>(pv);
+      }
+      l += __shfl_xor(l, 32, 64);
+      float inv = 1.0f / l;
+      if (p.o_rowscale) inv *= p.o_rowscale[(long)(h / p.rs_hdiv) * p.rs_stride + (long)b * p.Lq + qrow];
+      // O^T = V^T . P^T over this head's own columns of the tile
+      const lds_u8* const vb = vt0 + j * (32 * VP) + (4 * hi + (gi >> 2)) * VP + (gi & 3) * 8;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        const int cb = min(db * 32 + gdh * 16, HDP - 16) * 2;
+        f32x16 o;
+        {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + cb));
+          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * VP + cb));
+          o = Vec<T>::mfma32(__builtin_bit_cast(V8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7)), pf[0], zero16);
+        }
+        {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 16 * VP + cb));
+          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 24 * VP + cb));
+          o = Vec<T>::mfma32(__builtin_bit_cast(V8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7)), pf[1], o);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = db * 32 + 8 * g + 4 * hi;
+          if (d0 < HD) {
+            V4 w;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) w[jj] = from_f32<T>(o[4 * g + jj] * inv);
+            *reinterpret_cast<V4*>(trow + (col0 + d0) * 2) = w;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- tile -> out ----
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int q = tid + NT * i, r = q / CPR, cc = q - r * CPR;
+      const V8 v = *reinterpret_cast<const V8*>(tile + r * PITCH + cc * 16);
+      if (row0 + r < p.Lq) st8<T>(Og + (long)(row0 + r) * p.o_rs + cc * 8, v);
+    }
+    __syncthreads();
+  }
+}
+
+static int g_tok_attn = 1;        // hallo_set_option("tok_attn", 0 | 1): token cross-attention kernel for K/V of <= 32 rows (A/B)
+static int g_last_attn = 0;       // hallo_get_option("last_attn_kernel"): 1 flash kernel of this file, 2 attention40.hip, 3 tok_attn_kernel
+
+template <typename T, int HD>
+static int launch_tok_attn_hd(const AttnArgs& a, hipStream_t st) {
+  constexpr int HG = (HD == 40) ? 8 : (HD == 80 ? 4 : 2);
+  constexpr int NT = (HD == 160) ? 128 : 256;
+  const int groups = a.heads / HG;
+  const int ntiles = (a.Lq + 31) / 32;
+  // about the workgroups the LDS footprint keeps resident (3 per CU at 45 KB); each walks >= 1 tile
+  const int target = (HD == 160 ? 1024 : 768);
+  int parts = (target + a.batch * groups - 1) / (a.batch * groups);
+  if (parts > ntiles) parts = ntiles;
+  if (parts < 1) parts = 1;
+  hipLaunchKernelGGL((tok_attn_kernel<T, HD>), dim3((unsigned)(a.batch * groups * parts)), dim3(NT), 0, st, a, groups, parts, ntiles);
+  HALLO_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+static int launch_tok_attn(const AttnArgs& a, int hd, hipStream_t st) {
+  if (hd == 40) return launch_tok_attn_hd<T, 40>(a, st);
+  if (hd == 80) return launch_tok_attn_hd<T, 80>(a, st);
+  return launch_tok_attn_hd<T, 160>(a, st);
+}
+
 static int g_temporal_mfma = 1;   // hallo_set_option("temporal_mfma", 0 | 1)
 static int g_attn_order = 2;      // hallo_set_option("attn_order", 0 query-block-fastest | 1 head-fastest | 2 auto: head-fastest for K/V of <= 128 rows)
 static int g_attn40 = 1;          // hallo_set_option("attn40", 0 | 1): head-dim-40 pre-scaled-q launches on attention40.hip
@@ -694,9 +872,22 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
   const auto al16 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
   const bool kv_aligned = al16(d->k1) && al16(d->v1) && !((d->k1_bs | d->v1_bs | d->k1_rs | d->v1_rs) & 7) &&
                           (!d->k2 || (al16(d->k2) && al16(d->v2) && !((d->k2_bs | d->v2_bs | d->k2_rs | d->v2_rs) & 7)));
+  // token cross-attention: K/V of <= 32 rows, one segment, pre-scaled q, whole head groups, everything 16-byte aligned
+  {
+    const int hgp = d->head_dim == 40 ? 8 : (d->head_dim == 80 ? 4 : 2);
+    if (g_tok_attn && !d->k2 && d->Lkv1 <= 32 && d->q_prescaled != 0 && (d->dtype == DT_F16 || d->dtype == DT_BF16) && kv_aligned &&
+        d->heads % hgp == 0 && al16(d->q) && al16(d->o) && !((d->q_bs | d->o_bs | d->o_rs) & 7)) {
+      g_last_attn = 3;
+      if (d->dtype == DT_F16) return launch_tok_attn<_Float16>(a, d->head_dim, st);
+      return launch_tok_attn<__bf16>(a, d->head_dim, st);
+    }
+  }
   if (g_attn40 && d->head_dim == 40 && d->q_prescaled != 0 && (d->dtype == DT_F16 || d->dtype == DT_BF16) && kv_aligned &&
-      !(d->o_rs & 7) && !(d->o_bs & 7) && al16(d->o))
+      !(d->o_rs & 7) && !(d->o_bs & 7) && al16(d->o)) {
+    g_last_attn = 2;
     return launch_attn40(a, d->dtype, st);          // attention40.hip: LDS-DMA staging + transposing V reads
+  }
+  g_last_attn = 1;
   if (d->dtype == DT_F16) return launch_attn<_Float16>(a, d->head_dim, d->q_prescaled != 0, st);
   if (d->dtype == DT_BF16) return launch_attn<__bf16>(a, d->head_dim, d->q_prescaled != 0, st);
   return -22;
@@ -706,6 +897,8 @@ extern "C" int hallo_get_option_attn(const char* name) {
   if (name && !strcmp(name, "attn40")) return g_attn40;
   if (name && !strcmp(name, "temporal_mfma")) return g_temporal_mfma;
   if (name && !strcmp(name, "attn_order")) return g_attn_order;
+  if (name && !strcmp(name, "tok_attn")) return g_tok_attn;
+  if (name && !strcmp(name, "last_attn_kernel")) return g_last_attn;
   return -22;
 }
 
@@ -715,6 +908,7 @@ extern "C" int hallo_set_option_attn(const char* name, int value) {
   if (name && !strcmp(name, "temporal_mfma")) { if (value < 0 || value > 1) return -22; g_temporal_mfma = value; return 0; }
   if (name && !strcmp(name, "attn_order")) { if (value < 0 || value > 2) return -22; g_attn_order = value; return 0; }
   if (name && !strcmp(name, "attn40")) { if (value < 0 || value > 8) return -22; g_attn40 = value; set_attn40_variant(value); return 0; }
+  if (name && !strcmp(name, "tok_attn")) { if (value < 0 || value > 1) return -22; g_tok_attn = value; return 0; }
   if (name && !strcmp(name, "xattn_tiled")) return hallo_set_option_xattn(name, value);     // fused_xattn.hip
   return -22;
 }

@@ -396,6 +396,49 @@ def test_attention_audio_branches_one_launch(dtype, hd, L, report):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd,L,T,n", [(40, 300, 32, 3), (40, 4096, 32, 2), (80, 1024, 32, 3), (160, 256, 32, 3), (40, 200, 4, 2), (80, 96, 17, 2),
+                                      (160, 33, 1, 2)])
+def test_token_cross_attention_kernel(dtype, hd, L, T, n, report):
+    """K/V of <= 32 rows with a pre-scaled q (the form the UNet runs: the three audio branches x 8 heads as one launch, per-branch
+    fp32 row scale, output into a column slice of a wider buffer) take tok_attn_kernel (csrc/attention.hip): query tiles staged
+    through LDS, persistent over the tiles of a (frame, head group).  Against the fp32 expression, against the flash kernels
+    it replaces (hallo_set_option("tok_attn", 0)), ragged last tiles, 1 / 4 / 17 / 32 tokens, run-to-run identical."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(hd + 7 * L + T)
+    H = 8
+    D = H * hd
+    q3 = _rand((n, L, 3 * D), dtype, g)
+    kv3 = _rand((n, T, 6 * D), dtype, g)
+    rs = (torch.rand((3, n * L), generator=g) * 1.5).to(_dev())
+    qs = (q3.float() * ops.q_scale(hd)).to(dtype)
+    def run():
+        buf = torch.full((n * L, 3 * D + 8), 7.0, device=_dev(), dtype=dtype)
+        o = ops.attention(qs, kv3[:, :, :3 * D], kv3[:, :, 3 * D:], 3 * H, out=buf.view(n, L, 3 * D + 8)[:, :, :3 * D],
+                          rowscale=rs, rowscale_head_div=H, q_prescaled=True)
+        return buf, o
+    buf, out = run()
+    assert ops.get_option("last_attn_kernel") == 3, ops.get_option("last_attn_kernel")
+    for i in range(3):
+        # fp32 expression on the ROUNDED pre-scaled q (what the kernel sees): scores are in log2 units, softmax_2(s) = softmax(s ln 2)
+        p = torch.softmax((qs[:, :, i * D:(i + 1) * D].float().view(n, L, H, hd).transpose(1, 2)
+                           @ kv3[:, :, i * D:(i + 1) * D].float().view(n, T, H, hd).permute(0, 2, 3, 1)) * 0.6931471805599453, dim=-1)
+        ref = (p @ kv3[:, :, (3 + i) * D:(4 + i) * D].float().view(n, T, H, hd).transpose(1, 2)).transpose(1, 2).reshape(n, L, D) * rs[i].view(n, L, 1)
+        _check(f"tok_attn[{hd},{L},{T}] branch {i}", out[:, :, i * D:(i + 1) * D], ref, dtype, report)
+    assert (buf[:, 3 * D:].float() == 7.0).all(), "columns outside the output slice must be untouched"
+    buf2, _ = run()
+    assert torch.equal(buf, buf2), "not bit-reproducible"
+    ops.set_option("tok_attn", 0)
+    try:
+        _, old = run()
+        assert ops.get_option("last_attn_kernel") in (1, 2)
+    finally:
+        ops.set_option("tok_attn", 1)
+    d = (old.float() - out.float()).norm() / out.float().norm()
+    assert d < (2e-3 if dtype == torch.float16 else 1.2e-2), float(d)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("hd,Lq,Lkv", [(40, 300, 700), (40, 64, 4), (80, 200, 333), (160, 100, 64)])
 def test_attention_prescaled_q(dtype, hd, Lq, Lkv, report):
     """q produced by a fused q|k|v GEMM whose q columns carry head_dim^-0.5 * log2(e) (hallo_gemm lead_alpha),
