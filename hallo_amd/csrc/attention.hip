@@ -660,6 +660,129 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const T* __rest
 }
 
 // -------------------------------------------------------------------------------------------
+// Temporal attention, LDS-staged form (round 3, 8 heads x head dim 40 / 80 = the 64 x 64 and 32 x 32 levels): one workgroup per
+// PIXEL.  The fused [q | k | v] row of a pixel and frame is 3C contiguous elements (1920 / 3840 bytes = 15 / 30 whole lines); the
+// kernel above lets each wave pick its head's 80 / 160-byte pieces out of those rows with one lane per frame, and stores 8 bytes
+// per lane.  Here the F rows go global -> LDS by whole-line 16-byte loads (pitch 6C + 16 bytes), the four waves take two heads
+// each with Q / K fragments and the transposed V reads straight from that tile (rows >= F clamp to the last frame: their
+// probabilities are zero), O^T is written over the head's own q columns and the C output elements of every frame leave as whole
+// lines.  Same MFMA / softmax sequence per (pixel, head) as above: the two kernels agree bit for bit.
+// -------------------------------------------------------------------------------------------
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void temporal_attn_tiled_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                                  int F, int HW, float scale_log2e) {
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  constexpr int HEADS = 8, C = HEADS * HD, C3 = 3 * C;
+  constexpr int PITCH = C3 * 2 + 16;                 // bytes
+  constexpr int HDP = ((HD + 15) / 16) * 16;
+  constexpr int NKS = HDP / 16, NDB = (HD + 31) / 32;
+  constexpr int CPR = C3 / 8, OPR = C / 8;           // 16-byte pieces per input / output row
+  constexpr int MAXU = (19 * CPR + 255) / 256;       // pieces per thread with every load in flight (F <= 19; a tail loop covers more)
+  extern __shared__ __attribute__((aligned(16))) unsigned char tt_smem[];
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  unsigned char* const tile = tt_smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const long bp = xcd_remap((int)blockIdx.x, (int)gridDim.x);       // b * HW + pixel
+  const int pix = (int)(bp % HW);
+  const long b = bp / HW;
+  const long fstride = (long)HW * C3;
+  const T* base = qkv + ((b * F) * (long)HW + pix) * C3;
+
+  // ---- the F rows of this pixel -> LDS ----
+  {
+    const int total = F * CPR;
+    V8 tmp[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+      const int u = tid + 256 * i;
+      if (u < total) { const int f = u / CPR, cc = u - f * CPR; tmp[i] = ld8<T>(base + f * fstride + cc * 8); }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+      const int u = tid + 256 * i;
+      if (u < total) { const int f = u / CPR, cc = u - f * CPR; *reinterpret_cast<V8*>(tile + f * PITCH + cc * 16) = tmp[i]; }
+    }
+    for (int u = tid + 256 * MAXU; u < total; u += 256) {
+      const int f = u / CPR, cc = u - f * CPR;
+      *reinterpret_cast<V8*>(tile + f * PITCH + cc * 16) = ld8<T>(base + f * fstride + cc * 8);
+    }
+  }
+  __syncthreads();
+
+  const int fr = min(l31, F - 1);                     // rows >= F re-read the last frame, masked below
+  const int gi = lane & 15, gdh = (lane >> 4) & 1;
+  const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int h = wave + 4 * j;
+    unsigned char* const qrow = tile + fr * PITCH + h * HD * 2;
+    f32x16 s = zero16;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int d = ks * 16 + hi * 8;
+      const V8 qf = (d < HD) ? *reinterpret_cast<const V8*>(qrow + d * 2) : zero8<T>();
+      const V8 kf = (d < HD) ? *reinterpret_cast<const V8*>(qrow + (C + d) * 2) : zero8<T>();
+      s = Vec<T>::mfma32(kf, qf, s);
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jf = 8 * (r >> 2) + 4 * hi + (r & 3);
+      s[r] = (jf < F) ? s[r] : -3.0e38f;
+      mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mneg = -mx * scale_log2e;
+    float l = 0.0f;
+    V8 pf[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2e, mneg));
+      l += pv;
+      pf[r >> 3][r & 7] = from_f32<T>(pv);
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    // V^T fragments: frames 16 ks2 + 8 half + 4 hi + (gi >> 2), columns cb + 4 (gi & 3) ..; frames >= F clamp (their P is zero)
+    const lds_u8* const vcol = (const lds_u8*)tile + (2 * C + h * HD) * 2 + (gi & 3) * 8;
+    auto vread = [&](int frame, int cb) {
+      return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vcol + min(frame, F - 1) * PITCH + cb));
+    };
+    const int frow = 4 * hi + (gi >> 2);
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      const int cb = min(db * 32 + gdh * 16, HDP - 16) * 2;
+      const s16x8 v0 = __builtin_shufflevector(vread(frow, cb), vread(frow + 8, cb), 0, 1, 2, 3, 4, 5, 6, 7);
+      const s16x8 v1 = __builtin_shufflevector(vread(frow + 16, cb), vread(frow + 24, cb), 0, 1, 2, 3, 4, 5, 6, 7);
+      f32x16 o = Vec<T>::mfma32(__builtin_bit_cast(V8, v0), pf[0], zero16);
+      o = Vec<T>::mfma32(__builtin_bit_cast(V8, v1), pf[1], o);
+      if (l31 < F) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = db * 32 + 8 * g + 4 * hi;
+          if (d0 < HD) {
+            V4 w;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) w[jj] = from_f32<T>(o[4 * g + jj] * inv);
+            *reinterpret_cast<V4*>(qrow + d0 * 2) = w;          // over this head's own q columns
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the C output elements of every frame leave as whole lines ----
+  for (int u = tid; u < F * OPR; u += 256) {
+    const int f = u / OPR, cc = u - f * OPR;
+    st8<T>(out + ((b * F + f) * (long)HW + pix) * C + cc * 8, *reinterpret_cast<const V8*>(tile + f * PITCH + cc * 16));
+  }
+}
+
+// -------------------------------------------------------------------------------------------
 // Token cross-attention (round 3): K/V of <= 32 rows -- the 32 audio tokens of a frame (hallo/models/attention.py:853-903,
 // the three masked branches x 8 heads as one launch) or the 4 face tokens on the unfused path -- against thousands of query
 // rows.  The flash kernels above give such a launch one workgroup per (query block, HEAD): a lane owns a query row and reads
@@ -837,7 +960,7 @@ static int launch_tok_attn(const AttnArgs& a, int hd, hipStream_t st) {
   return launch_tok_attn_hd<T, 160>(a, st);
 }
 
-static int g_temporal_mfma = 1;   // hallo_set_option("temporal_mfma", 0 | 1)
+static int g_temporal_mfma = 2;   // hallo_set_option("temporal_mfma", 0 | 1 | 2): 0 VALU kernel, 1 one wave per (pixel, head), 2 (default) + the LDS-staged per-pixel kernel at 8 heads x head dim 40 / 80
 static int g_attn_order = 2;      // hallo_set_option("attn_order", 0 query-block-fastest | 1 head-fastest | 2 auto: head-fastest for K/V of <= 128 rows)
 static int g_attn40 = 1;          // hallo_set_option("attn40", 0 | 1): head-dim-40 pre-scaled-q launches on attention40.hip
 
@@ -905,7 +1028,7 @@ extern "C" int hallo_get_option_attn(const char* name) {
 extern "C" int hallo_set_option_xattn(const char* name, int value);
 
 extern "C" int hallo_set_option_attn(const char* name, int value) {
-  if (name && !strcmp(name, "temporal_mfma")) { if (value < 0 || value > 1) return -22; g_temporal_mfma = value; return 0; }
+  if (name && !strcmp(name, "temporal_mfma")) { if (value < 0 || value > 2) return -22; g_temporal_mfma = value; return 0; }
   if (name && !strcmp(name, "attn_order")) { if (value < 0 || value > 2) return -22; g_attn_order = value; return 0; }
   if (name && !strcmp(name, "attn40")) { if (value < 0 || value > 8) return -22; g_attn40 = value; set_attn40_variant(value); return 0; }
   if (name && !strcmp(name, "tok_attn")) { if (value < 0 || value > 1) return -22; g_tok_attn = value; return 0; }
@@ -919,6 +1042,30 @@ extern "C" int hallo_temporal_attention(const void* qkv, void* out, int B, int F
   if (C % heads || (C / heads) % 8) return -22;
   const int hd = C / heads;
   hipStream_t st0 = reinterpret_cast<hipStream_t>(stream);
+  if (g_temporal_mfma >= 2 && heads == 8 && (hd == 40 || hd == 80) && (dtype == DT_F16 || dtype == DT_BF16)) {
+    // LDS-staged form: one workgroup per pixel, F rows of 6C + 16 bytes (34.8 / 69.4 KB at 18 frames)
+    const float sl0 = scale * 1.4426950408889634f;
+    const size_t lds = (size_t)F * (3 * C * 2 + 16);
+    static bool attr_done[64][4] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -19;
+    const int slot = (dtype == DT_F16 ? 0 : 2) + (hd == 40 ? 0 : 1);
+#define HALLO_TTILED(TT, HDv)                                                                                                                  \
+    do {                                                                                                                                       \
+      if (!attr_done[dev][slot]) {                                                                                                             \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_tiled_kernel<TT, HDv>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                32 * (3 * 8 * HDv * 2 + 16)) != hipSuccess) return -19;                                                        \
+        attr_done[dev][slot] = true;                                                                                                           \
+      }                                                                                                                                        \
+      hipLaunchKernelGGL((temporal_attn_tiled_kernel<TT, HDv>), dim3((unsigned)((long)B * HW)), dim3(256), lds, st0,                            \
+                         reinterpret_cast<const TT*>(qkv), reinterpret_cast<TT*>(out), F, HW, sl0);                                            \
+    } while (0)
+    if (dtype == DT_F16) { if (hd == 40) HALLO_TTILED(_Float16, 40); else HALLO_TTILED(_Float16, 80); }
+    else { if (hd == 40) HALLO_TTILED(__bf16, 40); else HALLO_TTILED(__bf16, 80); }
+#undef HALLO_TTILED
+    HALLO_CHECK_LAUNCH();
+    return 0;
+  }
   if (g_temporal_mfma && (heads & 3) == 0 && (hd == 40 || hd == 80 || hd == 160) && (dtype == DT_F16 || dtype == DT_BF16)) {
     const float sl0 = scale * 1.4426950408889634f;
     dim3 grid((unsigned)((long)B * HW * (heads / 4))), block(256);

@@ -522,14 +522,22 @@ def test_attention_forced_rescale(dtype, report):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("Cd,HW,Fr,B", [(320, 64, 18, 1), (640, 16, 18, 2), (1280, 4, 18, 1), (320, 9, 10, 2)])
+@pytest.mark.parametrize("Cd,HW,Fr,B", [(320, 64, 18, 1), (640, 16, 18, 2), (1280, 4, 18, 1), (320, 9, 10, 2), (320, 1024, 18, 1), (640, 256, 18, 1),
+                                        (320, 33, 24, 2), (640, 7, 32, 1), (320, 5, 1, 2)])
 def test_temporal_attention(dtype, Cd, HW, Fr, B, report):
+    """8 heads x head dim 40 / 80 take the LDS-staged per-pixel kernel (whole-line loads and stores), head dim 160 the
+    one-wave-per-(pixel, head) kernel; where both apply they must agree bit for bit (temporal_mfma switch), 1 .. 32 frames."""
     from hallo_amd import ops
     from oracle import ops_ref
     g = torch.Generator().manual_seed(Cd + HW)
     qkv = _rand((B * Fr, HW, 3 * Cd), dtype, g)
     out = ops.temporal_attention(qkv, B, Fr, HW, Cd, 8)
     _check(f"temporal_attn[{Cd},{HW},{Fr},{B}]", out, ops_ref.temporal_attention(qkv, B, Fr, HW, Cd, 8), dtype, report)
+    ops.set_option("temporal_mfma", 1)
+    try:
+        assert torch.equal(ops.temporal_attention(qkv, B, Fr, HW, Cd, 8), out)
+    finally:
+        ops.set_option("temporal_mfma", 2)
 
 
 # --------------------------------------------------------------------------------------------
