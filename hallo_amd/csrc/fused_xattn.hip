@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void face_xattn_kernel(const XattnArgs p) {
 // two kernels agree bit for bit (tests/test_ops_gpu.py compares them).
 // ------------------------------------------------------------------------------------------------------------------------
 template <typename T, int C>
-__global__ __launch_bounds__(256) void face_xattn_tiled_kernel(const XattnArgs p, int nblocks) {
+__global__ __launch_bounds__(256, C == 320 ? 3 : (C == 640 ? 2 : 1)) void face_xattn_tiled_kernel(const XattnArgs p, int nblocks) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   constexpr int PITCH = C * 2 + 16;              // bytes
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void face_xattn_tiled_kernel(const XattnArgs p
 
   V8 sgf[NKW];               // Sg[(h,t) = l31][ks * 16 + hi * 8 ..], ks = wave + 4 j
   V8 ow0[NCW], ow1[NCW];     // OwP[c = cb * 32 + l31][hi * 8 ..] and [16 + hi * 8 ..], cb = wave + 4 j
-  float gv[4][4], bv[4][4];
+  __shared__ float s_gb[2][32];                                // G / B of the current batch (LDS: 32 registers fewer than copies per lane)
   long cur_b = -1;
 
   for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
@@ -194,13 +194,8 @@ __global__ __launch_bounds__(256) void face_xattn_tiled_kernel(const XattnArgs p
           ow1[j] = ld8<T>(wrow + 16);
         }
       }
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          gv[g][jj] = p.g[bidx * 32 + 8 * g + 4 * hi + jj];
-          bv[g][jj] = p.b[bidx * 32 + 8 * g + 4 * hi + jj];
-        }
+      __syncthreads();                                         // previous block's readers of s_gb are done (block-uniform branch)
+      if (threadIdx.x < 32) { s_gb[0][threadIdx.x] = p.g[bidx * 32 + threadIdx.x]; s_gb[1][threadIdx.x] = p.b[bidx * 32 + threadIdx.x]; }
     }
 
     // ---- 1. x block -> LDS ----
@@ -252,7 +247,7 @@ __global__ __launch_bounds__(256) void face_xattn_tiled_kernel(const XattnArgs p
     for (int g = 0; g < 4; ++g) {
       float sc[4];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) sc[jj] = __builtin_fmaf(rstd, s[4 * g + jj] - mean * gv[g][jj], bv[g][jj]);
+      for (int jj = 0; jj < 4; ++jj) sc[jj] = __builtin_fmaf(rstd, s[4 * g + jj] - mean * s_gb[0][8 * g + 4 * hi + jj], s_gb[1][8 * g + 4 * hi + jj]);
       const float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
       float e4[4], l = 0.0f;
 #pragma unroll
@@ -317,9 +312,10 @@ extern "C" int hallo_face_xattn(const void* x, void* y, const void* sg, const fl
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((unsigned)((rows + 31) / 32)), block(256);
   if (g_xattn_tiled && (C == 320 || C == 640 || C == 1280) && (dtype == DT_F16 || dtype == DT_BF16)) {
-    // persistent: <= 2 workgroups per CU in flight walk the 32-row blocks (the per-batch constants load once per workgroup)
+    // persistent: the workgroups a CU keeps resident walk the 32-row blocks (the per-batch constants load once per workgroup)
     const int nblocks = (int)grid.x;
-    const dim3 pg((unsigned)(nblocks < 512 ? nblocks : 512));
+    const int cap = C == 320 ? 768 : 512;             // resident workgroups: 3 per CU at C = 320 (160 registers, 39 KB), 2 at 640, 1 at 1280
+    const dim3 pg((unsigned)(nblocks < cap ? nblocks : cap));
 #define HALLO_XT(TT, CC) hipLaunchKernelGGL((face_xattn_tiled_kernel<TT, CC>), pg, block, 0, st, a, nblocks)
     if (dtype == DT_F16) { if (C == 320) HALLO_XT(_Float16, 320); else if (C == 640) HALLO_XT(_Float16, 640); else HALLO_XT(_Float16, 1280); }
     else { if (C == 320) HALLO_XT(__bf16, 320); else if (C == 640) HALLO_XT(__bf16, 640); else HALLO_XT(__bf16, 1280); }
