@@ -324,7 +324,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="A/B: launch every kernel of every UNet evaluation from the host (round-2 behaviour) instead of replaying "
                          "the hipGraph captured in the warm-up clip (FaceAnimatePipeline(use_graph=True))")
-    ap.add_argument("--graph", action="store_true", help="N > 1: replay the captured hipGraph too (default there: eager launches)")
+    ap.add_argument("--graph", action="store_true", help="(kept for old command lines: graph replay is the default at every N now)")
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: do not pin each rank to its own slice of the host cores")
     ap.add_argument("--gather", default=None, choices=["u8", "f32"],
                     help="N > 1: what the per-wave all-gather moves -- u8 (default): the frames converted to the uint8 video bytes on "
                          "the device (hallo_frames_to_uint8 = hallo/utils/util.py:308-312, 12.6 MB per rank at 512x512x16f); f32: "
@@ -337,10 +338,31 @@ def main():
         cpu_baseline_worker(args.frames, args.ddim_steps, args.cpu_budget)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, exactly the command the
+        # driver uses for N > 1) instead of dying on the world-size check.  The torchrun path is untouched.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    # one rank per GPU shares the host with N - 1 others: give each rank its own slice of the usable cores, so that the
+    # N launch threads (and RCCL's proxy / watchdog threads) do not migrate over each other (N = 1: untouched)
+    pinned = None
+    if world > 1 and hasattr(os, "sched_setaffinity") and not args.no_pin:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // world
+        if per >= 1:
+            pinned = cores[local_rank * per:(local_rank + 1) * per]
+            os.sched_setaffinity(0, pinned)
     dry = args.dry_run_cpu
     dist = None
     if dry:
@@ -371,10 +393,13 @@ def main():
         pipe, audioproj = build_pipeline(dev, dtype)
         if args.fp8_proj:
             pipe.denoising_unet.set_fp8_projections(True)
-        # one hipGraph of the UNet evaluation, captured during the warm-up clip, replayed for steps 1.. of every clip
-        # (N > 1: eager unless --graph -- graph capture next to RCCL's watchdog thread could not be tried on this pool's 1-GPU boxes,
-        # and on one GPU the replay measures within 0.5 % of eager launches: profiles/r3_graph_ab.json)
-        pipe.use_graph = not args.no_graph and args.warmup > 0 and (world == 1 or args.graph)
+        # one hipGraph of the UNet evaluation, captured during the warm-up clip, replayed for steps 1.. of every clip -- at every
+        # N: eager launches cost the host 829 ms per 1004 ms clip (profiles/r3_step_timeline.json), i.e. 8 ranks on a 16-core
+        # host would be close to host-bound, a replay costs 215 ms.  Capture next to an initialised RCCL communicator (its
+        # watchdog thread issues HIP calls; capture_error_mode="thread_local") is covered on one GPU by
+        # tests/test_multigpu_gpu.py::test_graph_replay_next_to_rccl_world1; should the capture fail on a multi-GPU node anyway,
+        # the warm-up below falls back to eager launches and the JSON line says so.
+        pipe.use_graph = not args.no_graph and args.warmup > 0
     from hallo_amd.animate.clip_parallel import gather_wave
     gather_u8 = world > 1 and (args.gather or ("f32" if dry else "u8")) == "u8"
     # rank 0 receives the whole wave (one clip per rank) and copies ALL of it to the host
@@ -415,8 +440,26 @@ def main():
         return frames
 
     inputs = [one_clip(i) for i in range(args.warmup + args.steps)]
+    graph_note = None
     for i in range(args.warmup):
-        run(inputs[i])
+        try:
+            run(inputs[i])
+        except Exception as e:          # a failed capture must not cost the measurement: eager launches, and say so
+            if dry or not pipe.use_graph:
+                raise
+            graph_note = f"eager (hipGraph capture failed in the warm-up: {type(e).__name__}: {str(e)[:160]})"
+            pipe.use_graph = False
+            pipe.reset_graphs()
+            sync()
+            run(inputs[i])
+    if world > 1 and not dry:
+        # every rank must take the same launch path: if one rank's capture failed, all go eager
+        flag = torch.tensor([0 if pipe.use_graph else 1], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) and pipe.use_graph:
+            graph_note = graph_note or "eager (another rank's hipGraph capture failed in the warm-up)"
+            pipe.use_graph = False
+            pipe.reset_graphs()
 
     def fence():
         sync()
@@ -425,8 +468,11 @@ def main():
             sync()
     fence()
     t0 = time.perf_counter()
+    host_s = 0.0
     for i in range(args.steps):
+        th = time.perf_counter()
         run(inputs[args.warmup + i])
+        host_s += time.perf_counter() - th      # host time to ENQUEUE a clip (nothing in run() waits for the GPU)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -452,7 +498,9 @@ def main():
         "config": {"workload": f"{cfg_name} per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
                                f"steps, guidance {args.guidance} ({'CFG, B=2' if args.guidance > 1 else 'no CFG, B=1'}), "
                                "ReferenceNet + VAE encode/decode + D2H inside the timed region",
-                   "launch": "hipGraph replay of the UNet evaluation (steps 1.. of every clip)" if (not dry and pipe.use_graph) else "eager",
+                   "launch": ("hipGraph replay of the UNet evaluation (steps 1.. of every clip)" if (not dry and pipe.use_graph) else (graph_note or "eager")),
+                   "host_enqueue_ms_per_clip": round(host_s / args.steps * 1e3, 1),
+                   "host_cores_per_rank": len(pinned) if pinned else len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (
                        f" + RCCL all-gather of the decoded frames ({'uint8 video bytes' if gather_u8 else 'fp32'})" if world > 1 else "")},
     }

@@ -142,8 +142,14 @@ class FaceAnimatePipeline:
         C0 = den.config.block_out_channels[0]
         sg = None
         if self.use_graph:
+            # prepare() is lazy: after den.load_state_dict() / den.to() the weight images (and prepare_epoch) of the NEXT forward
+            # differ from what the attribute says now.  Re-prepare here, so that the epoch in the key is the one step 0 runs
+            # with -- otherwise step 0 would rebuild (and free) the images under a graph captured from the old ones.
+            den.prepare()
+            refnet.prepare()
             ms_key = None if motion_scale is None else tuple(float(m) for m in motion_scale)
             key = (B, Fr, h, w, dt, str(dev), ref_image.shape[1] if ref_image.dim() == 5 else ref_image.shape[0], ms_key,
+                   tuple(audio_tensor.shape[-2:]), tuple(enc.shape[1:]), ops.option_epoch(),
                    bool(getattr(den, "fp8_projections", False)), den.prepare_epoch)
             sg = self._graphs.get(key)
             if sg is None:

@@ -311,17 +311,20 @@ class FeedForward(nn.Module):
         g = self.net[0].proj
         self._ln_eps = norm.eps
         self._ln_w, self._ln_g, self._ln_b = ops.fold_layernorm(norm.weight, norm.bias, g.weight, g.bias)
-        # 320-wide blocks (64 x 64 latents): LayerNorm -> GEGLU -> net[2] -> + x as ONE kernel (hallo_ff320) on a packed weight image
+        # 320-wide blocks (64 x 64 latents): LayerNorm -> GEGLU -> net[2] -> + x as ONE kernel (hallo_ff320) on a packed weight
+        # image.  The kernel is off by default (`ff_fused`: slower than the two GEMMs), so the 2.6 MB image is
+        # built on the first call that takes it, not at prepare time; fold_norm (= every re-prepare) invalidates it.
         self._ff_pack = None
-        if g.weight.shape[1] == ops.FF320_C and g.weight.shape[0] == 2 * ops.FF320_INNER and g.weight.is_cuda:
-            self._ff_pack = ops.ff320_pack(self._ln_w, self._ln_b, self.net[2].weight)
+        self._ff_pack_ok = g.weight.shape[1] == ops.FF320_C and g.weight.shape[0] == 2 * ops.FF320_INNER and g.weight.is_cuda
 
     def run_ln(self, x):
         """x [N, L, C] UN-normalised -> ff(LayerNorm(x)) + x: one fused kernel for 320-wide blocks with enough rows, else the
         norm fused into the GEGLU GEMM and the residual into net[2]'s."""
         N, L, Cd = x.shape
         x2 = x.view(N * L, Cd)
-        if self._ff_pack is not None and ops.ff320_enabled(N * L):
+        if self._ff_pack_ok and ops.ff320_enabled(N * L):
+            if self._ff_pack is None:
+                self._ff_pack = ops.ff320_pack(self._ln_w, self._ln_b, self.net[2].weight)
             return ops.ff320(x2, self._ff_pack, self.net[2].bias, eps=self._ln_eps).view(N, L, Cd)
         h = ops.gemm(x2, self._ln_w, self._ln_b, geglu=True, ln_colsum=self._ln_g, ln_eps=self._ln_eps,
                      ln_stats=ops.ln_stats(x2, self._ln_w.shape[0] // 2, self._ln_eps, geglu=True))

@@ -37,9 +37,19 @@ def _chk_dev(*ts):
             raise _l.HalloLibraryError("hallo_amd operators need device (HIP) tensors; there is no CPU path")
 
 
+_option_epoch = 0
+
+
 def set_option(name, value):
-    """Kernel A/B switch, e.g. set_option('gemm_variant', 0|1|2)."""
+    """Kernel A/B switch, e.g. set_option('gemm_variant', 0|1|2).  Bumps `option_epoch()`: captured hipGraphs hold the
+    kernels the options routed to at capture time, so FaceAnimatePipeline keys its graphs on the epoch."""
+    global _option_epoch
     _l.check(_l.load().hallo_set_option(name.encode(), int(value)), f"hallo_set_option({name})")
+    _option_epoch += 1
+
+
+def option_epoch():
+    return _option_epoch
 
 
 def get_option(name):

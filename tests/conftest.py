@@ -2,7 +2,13 @@ import json
 import os
 import sys
 
-import pytest
+# Pin ATen's CPU kernel dispatch BEFORE torch is imported: the AVX2 and AVX-512 builds of torch.randn's kernel differ in
+# the last ulp, which made the synthetic weights of the parity tests host-dependent (a few elements next to a bf16 rounding
+# boundary) and forced an approximate fingerprint rule on the stored oracle outputs of tests/golden/*.npz.  With the AVX2
+# kernels on every x86 host the weights are bit-identical (tests/test_full_size_gpu.py::same_data).  CPU-side only.
+os.environ.setdefault("ATEN_CPU_CAPABILITY", "avx2")
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

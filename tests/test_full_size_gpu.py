@@ -26,6 +26,8 @@ pytestmark = pytest.mark.gpu
 # stored output is used only when the weights and inputs rebuilt here fingerprint like the ones it was made from;
 # otherwise the oracle is evaluated on the spot (minutes of CPU per case).
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_golden.npz")
+# the multi-step trajectories at the benchmarked size (round 4): 512 x 512 x 16 frames x 25 steps (B = 1) and x 40 steps x CFG 3.5
+GOLDEN_TRAJ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trajectory_golden.npz")
 
 DEV = "cuda:0"
 ARCH = "full"
@@ -64,29 +66,49 @@ def _native(dtype):
 
 
 def fingerprint(tensors):
-    """Fingerprint of a list of fp32 tensors: element count, the exact int64 sum of the bit patterns (associative: thread count /
-    vector width cannot change it) and fp64 moments.  `same_data` accepts equal bit sums, or moments equal to 1e-4 relative:
-    torch.randn's CPU kernels differ in the last ulp between vector ISAs (AVX2 / AVX-512 hosts), which moves a few hundred of
-    the 4e7 bf16-rounded synthetic inputs by one bf16 ulp -- nothing against tolerances of 1e-2, and no reason to throw a
-    stored oracle output away -- while another seed or shape moves the moments by percent."""
+    """Fingerprint of a list of fp32 tensors: element count, the exact int64 sum of the bit patterns (associative: thread
+    count / vector width cannot change it), one such bit sum PER TENSOR (`per`) and fp64 moments (diagnostics only)."""
     bits = s1 = s2 = 0
     n = 0
+    per = []
     for t in tensors:
         t = t.detach().float().contiguous()
-        bits = (bits + int(t.view(torch.int32).to(torch.int64).sum())) & 0xFFFFFFFFFFFFFFFF
+        b = int(t.view(torch.int32).to(torch.int64).sum())
+        per.append(b)
+        bits = (bits + b) & 0xFFFFFFFFFFFFFFFF
         s1 += float(t.double().sum())
         s2 += float(t.double().abs().sum())
         n += t.numel()
-    return {"n": n, "bits": bits, "sum": s1, "abs": s2}
+    return {"n": n, "bits": bits, "sum": s1, "abs": s2, "per": per}
+
+
+MAX_INEXACT_TENSORS = 8      # tensors whose bit sum may differ at all between the generating host and this one
+MAX_GRID_STEPS = 4           # ... by at most this many steps of the shared fp16/bf16 grid (2^16 in the fp32 bit pattern)
 
 
 def same_data(a, b):
+    """"exact": identical element count and bit sum (the case tests/conftest.py arranges: ATEN_CPU_CAPABILITY=avx2 pins
+    torch.randn's CPU kernel, whose AVX2 and AVX-512 builds differ in the last ulp, so the synthetic weights are
+    bit-identical on every x86 host -- checked: this container's AVX-512 host reproduces the AVX2-made fingerprints of
+    round 3 bit for bit).  "inexact": the total bit sum differs, but only because at most MAX_INEXACT_TENSORS tensors moved
+    by at most MAX_GRID_STEPS one-step flips on the fp16/bf16 grid each (what a last-ulp difference in randn does to a value
+    next to a rounding boundary) and the fp64 moments agree to 1e-8 relative.  Anything else -- another seed, a re-drawn
+    layer (its bit sum moves by ~sqrt(n) * 2^22), another init rule -- is False: the stored oracle output does not belong
+    to this data (VERDICT r3 "weak": the old rule, moments to 1e-4 alone, would have accepted another seed)."""
     if a is None or b is None or a["n"] != b["n"]:
         return False
     if a["bits"] == b["bits"]:
-        return True
-    close = lambda x, y, ref: abs(x - y) <= 1e-4 * ref
-    return close(a["sum"], b["sum"], max(a["abs"], 1e-30)) and close(a["abs"], b["abs"], max(a["abs"], 1e-30))
+        return "exact"
+    pa, pb = a.get("per"), b.get("per")
+    if pa is None or pb is None or len(pa) != len(pb):
+        return False
+    diff = [x - y for x, y in zip(pa, pb) if x != y]
+    if not diff or len(diff) > MAX_INEXACT_TENSORS or any(d % 65536 or abs(d) > MAX_GRID_STEPS * 65536 for d in diff):
+        return False
+    close = lambda x, y, ref: abs(x - y) <= 1e-8 * ref
+    if close(a["sum"], b["sum"], max(a["abs"], 1e-30)) and close(a["abs"], b["abs"], max(a["abs"], 1e-30)):
+        return "inexact"
+    return False
 
 
 def _weights_fp(names):
@@ -97,30 +119,38 @@ def _weights_fp(names):
     return _CACHE[key]
 
 
-def _golden():
-    if "golden" not in _CACHE:
+def _golden(path=None):
+    path = path or GOLDEN
+    key = ("golden", path)
+    if key not in _CACHE:
         g = {}
-        if ARCH == "full" and os.path.exists(GOLDEN):
+        if ARCH == "full" and os.path.exists(path):
             import numpy as np
-            z = np.load(GOLDEN)
+            z = np.load(path)
             g = {"meta": json.loads(str(z["meta"])), "z": z}
-        _CACHE["golden"] = g
-    return _CACHE["golden"]
+        _CACHE[key] = g
+    return _CACHE[key]
 
 
-def golden_lookup(key, weight_nets, inputs):
-    """The stored oracle arrays of `key` if they were made from these weights and inputs, else None."""
-    g = _golden()
+def golden_lookup(key, weight_nets, inputs, path=None):
+    """The stored oracle arrays of `key` if they were made from these weights and inputs (`same_data`), else None.  Every
+    lookup is recorded in the parity report; the returned dict carries "oracle": "golden" | "golden-inexact"."""
+    g = _golden(path)
     m = g.get("meta", {}).get(key) if g else None
     if m is None:
         return None
     wf, inf = _weights_fp(weight_nets), fingerprint(inputs)
-    GOLDEN_LOG.append({"key": key, "weights_here": wf, "weights_stored": m["weights"], "inputs_here": inf, "inputs_stored": m["inputs"],
-                       "weights_exact": wf["bits"] == m["weights"]["bits"], "inputs_exact": inf["bits"] == m["inputs"]["bits"]})
-    if not (same_data(m["weights"], wf) and same_data(m["inputs"], inf)):
-        print(f"golden[{key}]: fingerprint mismatch -> evaluating the oracle here", GOLDEN_LOG[-1])
+    okw, oki = same_data(m["weights"], wf), same_data(m["inputs"], inf)
+    brief = lambda f: {k: v for k, v in f.items() if k != "per"}
+    GOLDEN_LOG.append({"key": key, "weights_here": brief(wf), "weights_stored": brief(m["weights"]), "inputs_here": brief(inf),
+                       "inputs_stored": brief(m["inputs"]), "weights_match": okw, "inputs_match": oki,
+                       "weights_exact": okw == "exact", "inputs_exact": oki == "exact", "cpu_capability": torch.backends.cpu.get_cpu_capability()})
+    if not (okw and oki):
+        print(f"golden[{key}]: fingerprint mismatch", GOLDEN_LOG[-1])
         return None
-    return {a: torch.from_numpy(g["z"][f"{key}/{a}"].astype("float32")) for a in m["arrays"]}
+    out = {a: torch.from_numpy(g["z"][f"{key}/{a}"].astype("float32")) for a in m["arrays"]}
+    out["oracle"] = "golden" if (okw == "exact" and oki == "exact") else "golden-inexact"
+    return out
 
 
 def _rb(t):
@@ -202,7 +232,7 @@ def _unet_case(B, Fr, h, use_golden=True):
     d = _unet_inputs(B, Fr, h)
     gold = golden_lookup(f"unet3d/B{B}_F{Fr}_h{h}", ("denoising_unet", "reference_unet"), _unet_input_list(d, B, h)) if use_golden else None
     if gold is not None:
-        d["out"], d["oracle"] = gold["out"], "golden"
+        d["out"], d["oracle"] = gold["out"], gold["oracle"]
     else:
         o = _oracle()
         ob = _oracle_banks(B, h)
@@ -371,7 +401,7 @@ def _pipe10_oracle():
     d, args, lat, flat, geo = _pipe10_inputs()
     gold = golden_lookup("pipeline10", PIPE_NETS, flat)
     if gold is not None:
-        res = dict(ts=[int(t) for t in gold["timesteps"]], latents=list(gold["latents"]), video=gold["video"], oracle="golden")
+        res = dict(ts=[int(t) for t in gold["timesteps"]], latents=list(gold["latents"]), video=gold["video"], oracle=gold["oracle"])
     else:
         o = _oracle()
         seen = []
@@ -411,6 +441,114 @@ def test_full_pipeline_config0_ten_steps(dtype, report):
     p = Hn.psnr(vid_n, ref["video"])
     report.append({"test": f"full_pipeline10_frames_psnr[{S}x{S}x{Fr}f,{steps} steps,gs={gs}]", "dtype": str(dtype),
                    "arch": ARCH, "psnr_db": p, "tol_psnr_db": 35.0})
+    print("PSNR", p)
+    assert p >= 35.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: parity of the TRAJECTORIES that are benchmarked / that the reference runs by default, at
+# full width and full size, through the hipGraph replay path bench.py times.
+#   pipeline25     512 x 512, 16 frames, 25 DDIM steps, guidance 1.0 (B = 1): BASELINE.json configs[1], bench.py's workload
+#   pipeline40cfg  512 x 512, 16 frames, 40 DDIM steps, CFG 3.5 (B = 2): the reference's default run
+#                  (configs/inference/default.yaml:4-18, hallo/animate/face_animate.py:383-427), BASELINE.json configs[2]
+# The fp32 CPU oracle needs ~1 min (B = 1) / ~2 min (B = 2) per step at this size: its per-step latents (fp16) and a subset
+# of the decoded frames are generated once in the authoring container (tests/golden/make_full_size_golden.py) and stored in
+# tests/golden/trajectory_golden.npz.  There is no live fallback at full size (it would take 25-80 minutes of the GPU box's
+# host): a fingerprint mismatch FAILS the test.
+TRAJ = {"pipeline25": dict(S=512, Fr=16, steps=25, gs=1.0, keep=list(range(1, 26)), frames=[0, 5, 10, 15]),
+        "pipeline40cfg": dict(S=512, Fr=16, steps=40, gs=3.5, keep=[1, 5, 10, 15, 20, 25, 30, 35, 40], frames=[0, 5, 10, 15])}
+SMALL_TRAJ = {"pipeline25": dict(S=128, Fr=4, steps=5, gs=1.0, keep=[1, 2, 3, 4, 5], frames=[0, 3]),
+              "pipeline40cfg": dict(S=128, Fr=4, steps=4, gs=3.5, keep=[1, 2, 4], frames=[0, 3])}
+
+
+def _traj_cfg(name):
+    return (TRAJ if ARCH == "full" else SMALL_TRAJ)[name]
+
+
+def _traj_inputs(name):
+    from oracle import harness as Hn
+    kw, _ = _arch()
+    c = _traj_cfg(name)
+    S, Fr, steps, gs = c["S"], c["Fr"], c["steps"], c["gs"]
+    d = Hn.clip_inputs(S, Fr, audio_dim=kw["audio_dim"], seed=4321 + steps)
+    args = (_rb(d["ref_image"]), _rb(d["face_emb"]), _rb(d["audio"]), d["face_mask"], [_rb(m) for m in d["full"]],
+            [_rb(m) for m in d["face"]], [_rb(m) for m in d["lip"]], S, S, Fr, steps, gs)
+    lat = _rb(d["latents"])
+    flat = [args[0], args[1], args[2], args[3]] + args[4] + args[5] + args[6] + [lat, torch.tensor(d["motion_scale"] + [float(steps), gs])]
+    return d, args, lat, flat
+
+
+def _traj_oracle_live(name, progress=None):
+    """The oracle's trajectory: {timesteps (all), latents of the kept steps, the kept decoded frames}."""
+    from oracle import hallo_ref as H
+    c = _traj_cfg(name)
+    d, args, lat, _ = _traj_inputs(name)
+    o = _oracle()
+    ts, kept = [], []
+
+    def cb(i, t, l):
+        ts.append(int(t))
+        if i + 1 in c["keep"]:
+            kept.append(l.clone())
+        if progress:
+            progress(i, int(t))
+    vid = H.animate(o["vae"], o["reference_unet"], o["denoising_unet"], o["face_locator"], o["imageproj"], H.make_scheduler(),
+                    *args, motion_scale=d["motion_scale"], latents=lat, callback=cb)
+    return dict(timesteps=torch.tensor(ts, dtype=torch.int32), latents=torch.stack(kept), video=vid[:, :, c["frames"]].contiguous())
+
+
+def _traj_oracle(name):
+    key = ("traj", name)
+    if key not in _CACHE:
+        if ARCH == "full":
+            _, _, _, flat = _traj_inputs(name)
+            gold = golden_lookup(name, PIPE_NETS, flat, path=GOLDEN_TRAJ)
+            if gold is None:
+                pytest.fail(f"{name}: no stored oracle trajectory for these weights / inputs in {GOLDEN_TRAJ} (fingerprints in the "
+                            "log above); regenerate with tests/golden/make_full_size_golden.py " + name)
+            _CACHE[key] = gold
+        else:
+            _CACHE[key] = dict(_traj_oracle_live(name), oracle="live")
+    return _CACHE[key]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("name", list(TRAJ))
+def test_full_pipeline_trajectory(dtype, name, report):
+    """FaceAnimatePipeline.__call__ (hallo/animate/face_animate.py:249-442) with use_graph=True -- step 0 eager, step 1
+    captured, steps 2.. replayed: the launch path bench.py times -- over the whole trajectory at the benchmarked size, against
+    the fp32 oracle: bit-exact schedule indices, rel-L2 of the latents after every kept step (bound 5e-2), PSNR of the
+    decoded frames (>= 35 dB)."""
+    from oracle import harness as Hn
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.scheduler import DDIMScheduler
+    c = _traj_cfg(name)
+    d, args, lat, _ = _traj_inputs(name)
+    ref = _traj_oracle(name)
+    n = _native(dtype)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    graph = DEV != "cpu"
+    pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched, use_graph=graph)
+    seen = []
+    vid_n = pipe(*args, motion_scale=d["motion_scale"], latents=lat,
+                 callback=lambda i, t, l: seen.append((int(t), l.float().cpu() if i + 1 in c["keep"] else None))).videos
+    if graph:
+        (sg,) = pipe._graphs.values()
+        assert sg.graph is not None and sg.replays == c["steps"] - 1
+    pipe.reset_graphs()
+    assert [t for t, _ in seen] == [int(t) for t in ref["timesteps"]] and len(seen) == c["steps"]
+    kept = [l for _, l in seen if l is not None]
+    assert len(kept) == len(ref["latents"]) == len(c["keep"])
+    per_step = [Hn.rel_l2(a, b) for a, b in zip(kept, ref["latents"])]
+    _rec(report, f"full_{name}_latents[{c['S']}x{c['S']}x{c['Fr']}f,{c['steps']} steps,gs={c['gs']}]", dtype, max(per_step), 5e-2,
+         steps_kept=c["keep"], per_step=[round(v, 6) for v in per_step], oracle=ref["oracle"], launch="hipGraph replay" if graph else "eager")
+    assert max(per_step) <= 5e-2, per_step
+    assert vid_n.shape == (1, 3, c["Fr"], c["S"], c["S"])
+    p = Hn.psnr(vid_n[:, :, c["frames"]], ref["video"])
+    report.append({"test": f"full_{name}_frames_psnr[{c['S']}x{c['S']}x{c['Fr']}f,{c['steps']} steps,gs={c['gs']}]", "dtype": str(dtype),
+                   "arch": ARCH, "psnr_db": p, "tol_psnr_db": 35.0, "frames_compared": c["frames"]})
     print("PSNR", p)
     assert p >= 35.0
 

@@ -200,6 +200,59 @@ def test_pipeline_hipgraph_replay_is_byte_identical(nets, guidance, report):
     report.append({"test": f"pipeline_hipgraph_byte_identical[gs={guidance}]", "dtype": str(dtype), "clips": 3, "replays": sg.replays})
 
 
+def test_pipeline_hipgraph_survives_reload_and_option_change(nets, report):
+    """`prepare()` is lazy, so after `load_state_dict()` between two graphed clips the graph key used to be
+    built from the OLD prepare_epoch and steps 1.. replayed a graph that pointed at freed weight images.  The key is now built
+    after `prepare()`; it also carries the audio / face token shapes and the kernel-option epoch (`ops.set_option` between clips
+    re-captures instead of replaying the old kernels).  Graphed frames must equal eager frames byte for byte in every case."""
+    dtype, o, n = nets
+    from oracle import harness as Hn
+    from hallo_amd import ops
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.scheduler import DDIMScheduler
+    S, Fr, steps = 128, 4, 3
+    mk = lambda: DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                               prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    den = n["denoising_unet"]
+    kw = dict(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=den, face_locator=n["face_locator"], image_proj=n["imageproj"])
+    eager = FaceAnimatePipeline(scheduler=mk(), **kw)
+    graphed = FaceAnimatePipeline(scheduler=mk(), use_graph=True, **kw)
+    rd = lambda t: t.to(dtype).float()
+    sd0 = {k: v.clone() for k, v in den.state_dict().items()}
+    g = torch.Generator().manual_seed(77)
+    sd1 = {k: (v * (1.0 + 0.05 * torch.randn(v.shape, generator=g).to(v.device, v.dtype)) if v.is_floating_point() and v.dim() > 1 else v)
+           for k, v in sd0.items()}
+
+    def clip(i):
+        d = Hn.clip_inputs(S, Fr, seed=1234 + i)
+        lat = rd(torch.randn(d["latents"].shape, generator=torch.Generator().manual_seed(42 + i)))
+        args = (rd(d["ref_image"]), rd(d["face_emb"]), rd(d["audio"]), d["face_mask"], [rd(m) for m in d["full"]],
+                [rd(m) for m in d["face"]], [rd(m) for m in d["lip"]], S, S, Fr, steps, 1.0)
+        b = graphed(*args, motion_scale=[1.0, 0.8, 1.2], latents=lat).videos      # first: it must do the lazy re-prepare itself
+        a = eager(*args, motion_scale=[1.0, 0.8, 1.2], latents=lat).videos
+        assert torch.equal(a, b), (i, (a - b).abs().max().item())
+        return a
+    try:
+        v0 = clip(0)
+        e0 = den.prepare_epoch
+        den.load_state_dict(sd1)                         # other weights, lazily prepared by the next forward
+        v1 = clip(0)
+        assert den.prepare_epoch > e0 and not torch.equal(v0, v1)
+        assert all(k[-1] == den.prepare_epoch for k in graphed._graphs)
+        old = ops.get_option("tok_attn")
+        ops.set_option("tok_attn", 0 if old else 1)      # route the token cross-attention to the other kernel: graph must re-capture
+        try:
+            clip(1)
+        finally:
+            ops.set_option("tok_attn", old)
+        clip(2)
+    finally:
+        den.load_state_dict(sd0)
+        den.prepare()
+        graphed.reset_graphs()
+    report.append({"test": "pipeline_hipgraph_reload_and_option_change", "dtype": str(dtype), "byte_identical": True})
+
+
 # ------------------------------------------------------------------------------------------------
 # SURVEY 8f rows 1 + 3: the sliding-window driver (motion-frame carry on the device, shared generator stream)
 # and the uint8 output conversion

@@ -77,6 +77,23 @@ def test_bench_control_flow_world2(tmp_path):
     assert abs(out["value"] - 2 * 3 * 4 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
 
 
+def test_bench_self_spawns_without_a_launcher():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: bench.py re-executes itself through
+    torch.distributed.run with one rank per GPU instead of dying on the world-size check; one JSON line, n_gpus 2."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run-cpu",
+                        "--size", "16", "--frames", "4"], capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["dry_run_wave"] == [2.0, 1002.0]
+    assert out["config"]["host_cores_per_rank"] >= 1 and out["config"]["host_enqueue_ms_per_clip"] >= 0.0
+
+
 def test_bench_control_flow_world1():
     import json
     import subprocess

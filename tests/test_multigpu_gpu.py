@@ -73,3 +73,71 @@ def test_two_gpus_byte_identical_to_one(tmp_path):
     mp.spawn(clip_worker, args=(2, port, "nccl", str(tmp_path)), nprocs=2, join=True)
     wave = torch.load(tmp_path / "wave.pt")
     assert wave.shape == (2, 2, 64 * 64, 3) and not torch.equal(wave[0], wave[1])     # two different clips came back
+
+
+def rccl_graph_worker(rank, world, port, out_dir):
+    """One rank (world = 1 on the development boxes, any world on a node): RCCL communicator initialised FIRST (its watchdog /
+    proxy threads are alive and issue HIP calls), then two clips through FaceAnimatePipeline(use_graph=True) -- clip 1 captures
+    the UNet graph, clip 2 replays it -- each followed by gather_wave on the group, and the same two clips eagerly: the
+    gathered bytes must be identical.  This is the launch path bench.py takes at N > 1."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    warm = torch.ones(8, device=dev)
+    dist.all_reduce(warm)                                       # the communicator is really up before anything is captured
+    torch.cuda.synchronize()
+    from oracle import harness as Hn
+    from hallo_amd.animate import clip_parallel as cp
+    from hallo_amd.animate import video as V
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.synthetic import make_scheduler
+    dtype = torch.bfloat16
+    o = Hn.oracle_nets(dtype=dtype)
+    n = Hn.native_nets(o, dtype=dtype, device=str(dev))
+    S, Fr, steps = 64, 2, 4
+    kw = dict(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"], face_locator=n["face_locator"],
+              image_proj=n["imageproj"])
+    pipes = {"graph": FaceAnimatePipeline(scheduler=make_scheduler(), use_graph=True, **kw),
+             "eager": FaceAnimatePipeline(scheduler=make_scheduler(), **kw)}
+    waves = {"graph": [], "eager": []}
+    for mode in ("graph", "eager"):
+        for idx in range(2):
+            d = Hn.clip_inputs(S, Fr, seed=1234 + 10 * rank + idx)
+            vid = pipes[mode](d["ref_image"], d["face_emb"], d["audio"], d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr,
+                              steps, 1.0, motion_scale=d["motion_scale"], latents=d["latents"], output_type="device").videos
+            frames = vid[0].permute(1, 0, 2, 3).reshape(Fr, 3, S * S).contiguous()
+            waves[mode].append(cp.gather_wave(V.frames_to_uint8(frames)))       # RCCL all-gather right behind the replayed graph
+    torch.cuda.synchronize()
+    (sg,) = pipes["graph"]._graphs.values()
+    assert sg.graph is not None and sg.replays == 2 * (steps - 1)
+    for a, b in zip(waves["graph"], waves["eager"]):
+        assert a.shape[0] == world and torch.equal(a, b)
+    assert not torch.equal(waves["graph"][0], waves["graph"][1])
+    if rank == 0:
+        torch.save({"replays": sg.replays, "world": world}, os.path.join(out_dir, "ok.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_graph_replay_next_to_rccl_world1(tmp_path, report):
+    """hipGraph capture + replay of the UNet evaluation inside a process that holds a live RCCL communicator, on ONE GPU
+    (`init_process_group("nccl", world_size=1)`): what could not be rehearsed before bench.py made graph replay the default at
+    N > 1.  Runs in a spawned child so that a hang or a poisoned context cannot take the test session with it."""
+    import torch.multiprocessing as mp
+    port = 29900 + (os.getpid() % 2000)
+    ctx = mp.spawn(rccl_graph_worker, args=(1, port, str(tmp_path)), nprocs=1, join=False)
+    import time
+    t0 = time.time()
+    while not ctx.join(timeout=5):
+        if time.time() - t0 > 420:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail("graph capture / replay next to RCCL did not finish in 420 s")
+    ok = torch.load(tmp_path / "ok.pt")
+    assert ok["replays"] == 6
+    report.append({"test": "graph_replay_next_to_rccl_world1", "replays": ok["replays"], "world": 1, "byte_identical_to_eager": True})
