@@ -62,6 +62,26 @@ class fast_init:
         return False
 
 
+def deterministic_pe(max_len, d_model):
+    """The motion modules' PositionalEncoding buffer (hallo/models/motion_module.py:426-461) with every transcendental of the
+    reference's expression evaluated in float64 and rounded ONCE to fp32 -- i.e. the correctly rounded value of the same fp32
+    formula (same fp32 arguments: the two products are single IEEE multiplies).  Why: `torch.sin / cos / exp` on fp32 CPU tensors
+    go through MKL's vector maths, which picks other code paths on AMD hosts than on Intel hosts; the results differ in the last
+    fp32 ulp, which moved one element per buffer across a bf16 rounding boundary between the authoring container (Xeon) and the GPU
+    box (EPYC 9575F) -- measured in round 4 with tools/weights_fingerprint.py: the 22 `pos_encoder.pe` buffers were the ONLY
+    tensors of the 2896 that differed, each by one grid step.  With this buffer the synthetic state dicts are bit-identical on
+    both hosts, so stored oracle outputs (tests/golden/*.npz) can be matched by exact fingerprints.  `pe` is a persistent buffer
+    (real checkpoints carry it), and oracle and native models receive the same values through the state dict."""
+    position = torch.arange(max_len).unsqueeze(1)
+    arg = torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model)
+    div_term = torch.exp(arg.double()).float()
+    x = position * div_term
+    pe = torch.zeros(1, max_len, d_model)
+    pe[0, :, 0::2] = torch.sin(x.double()).float()
+    pe[0, :, 1::2] = torch.cos(x.double()).float()
+    return pe
+
+
 def oracle_nets(cfg=SMALL, audio_dim=SMALL_AUDIO_DIM, vae_cfg=SMALL_VAE, dtype=torch.float16, seed=0,
                 zero_init_std=ZERO_INIT_STD):
     """Oracle modules (fp32 compute) whose weights are synthetic values rounded through `dtype` (or BOTH)."""
@@ -80,6 +100,11 @@ def oracle_nets(cfg=SMALL, audio_dim=SMALL_AUDIO_DIM, vae_cfg=SMALL_VAE, dtype=t
         # zero-init layers get std 0.1 (the order of their fan-in bound) so the audio / temporal / mask paths
         # each move the output by several times the parity tolerance (tests/test_oracle_cpu.py checks that)
         H.fill_synthetic_(m, seed + i + 1, zero_init_std=zero_init_std)
+        with torch.no_grad():
+            for bname, buf in m.named_buffers():
+                if bname.endswith("pos_encoder.pe"):
+                    assert buf.dtype == torch.float32 and (buf - deterministic_pe(buf.shape[1], buf.shape[2])).abs().max() < 1e-5
+                    buf.copy_(deterministic_pe(buf.shape[1], buf.shape[2]))
         m.load_state_dict(round_to(m.state_dict(), dtype))
         m.eval()
     return nets

@@ -91,7 +91,7 @@ def test_bench_self_spawns_without_a_launcher():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["dry_run_wave"] == [2.0, 1002.0]
-    assert out["config"]["host_cores_per_rank"] >= 1 and out["config"]["host_enqueue_ms_per_clip"] >= 0.0
+    assert out["config"]["host_cores_per_rank"] >= 1 and out["config"]["host_cpu_ms_per_clip"] >= 0.0
 
 
 def test_bench_control_flow_world1():

@@ -91,8 +91,8 @@ def rccl_graph_worker(rank, world, port, out_dir):
     dist.all_reduce(warm)                                       # the communicator is really up before anything is captured
     torch.cuda.synchronize()
     from oracle import harness as Hn
+    from hallo_amd import ops
     from hallo_amd.animate import clip_parallel as cp
-    from hallo_amd.animate import video as V
     from hallo_amd.animate.face_animate import FaceAnimatePipeline
     from hallo_amd.synthetic import make_scheduler
     dtype = torch.bfloat16
@@ -110,7 +110,7 @@ def rccl_graph_worker(rank, world, port, out_dir):
             vid = pipes[mode](d["ref_image"], d["face_emb"], d["audio"], d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr,
                               steps, 1.0, motion_scale=d["motion_scale"], latents=d["latents"], output_type="device").videos
             frames = vid[0].permute(1, 0, 2, 3).reshape(Fr, 3, S * S).contiguous()
-            waves[mode].append(cp.gather_wave(V.frames_to_uint8(frames)))       # RCCL all-gather right behind the replayed graph
+            waves[mode].append(cp.gather_wave(ops.frames_to_uint8(frames)))     # [F, HW, 3] uint8: RCCL all-gather right behind the replayed graph
     torch.cuda.synchronize()
     (sg,) = pipes["graph"]._graphs.values()
     assert sg.graph is not None and sg.replays == 2 * (steps - 1)
