@@ -53,7 +53,12 @@ class OpProfiler:
             fl, by = cost(a, k, r)
             shp = tuple(tuple(t.shape) for t in a[:3] if torch.is_tensor(t)) + ((("geglu",),) if k.get("geglu") else ()) \
                 + ((("res",),) if k.get("residual") is not None else ()) + ((("k2", tuple(k["k2"].shape)),) if k.get("k2") is not None else ())
-            self.records.append((name, s, e, fl, by, shp, self._symbol(name, a, k)))
+            sym = self._symbol(name, a, k)
+            if name in ("gemm", "conv3x3"):
+                from hallo_amd import ops as _o
+                sp = _o.get_option("last_gemm_splits")
+                shp = shp + (("sym", sym, "splits", sp),)
+            self.records.append((name, s, e, fl, by, shp, sym))
             return r
         return w
 
@@ -72,6 +77,8 @@ class OpProfiler:
             if kern == 4:      # row-stationary kernel (csrc/gemm_rs.hip): <T, K/16, W blocks per chunk, geglu, layernorm>
                 return "gemm_rs_kernel<%s,%d,%d,%s,%s>" % (dt, 20 if sub == 1 else 40, 4 if sub == 1 else 2,
                                                            "true" if mode == 2 else "false", "true" if lnf else "false")
+            if kern == 6:      # csrc/gemm4.hip: exact-fit / stream-K kernel of the 32x32 ... 8x8 levels
+                return "gemm4_kernel<%s>" % dt
             if kern == 5:      # csrc/gemm_rs2.hip (K = 320, epilogue sliced between the MFMAs): <T, geglu, layernorm, ablation>
                 return "gemm_rs2_kernel<%s,%s,%s,0>" % (dt, "true" if mode == 2 else "false", "true" if lnf else "false")
             return "gemm3_kernel<%s,%d,%d,%s>" % (dt, mode, sub & 3, "true" if sub & 4 else "false")
@@ -317,6 +324,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds of host time the CPU baseline may use")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B: hallo_set_option('gemm_variant', v) (default: library auto)")
+    ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B: hallo_set_option(NAME, VALUE) before the pipeline is built (e.g. gemm4=0); recorded in config.options")
     ap.add_argument("--shape-breakdown", action="store_true", help="write gpurun_out/shape_breakdown.json (per op x shape times)")
     ap.add_argument("--fp8-proj", action="store_true",
                     help="BASELINE.json configs[4]'s projection variant: q|k|v / out projections of the denoising UNet's "
@@ -389,6 +398,9 @@ def main():
         from hallo_amd import ops as _ops
         if args.gemm_variant is not None:
             _ops.set_option("gemm_variant", args.gemm_variant)
+        for kv in args.set_option:
+            k_, v_ = kv.split("=")
+            _ops.set_option(k_, int(v_))
         from hallo_amd.synthetic import build_pipeline, clip_inputs
         pipe, audioproj = build_pipeline(dev, dtype)
         if args.fp8_proj:
@@ -504,6 +516,7 @@ def main():
                    "host_wall_in_enqueue_calls_ms_per_clip": round(host_s / args.steps * 1e3, 1),
                    "host_cpu_ms_per_clip": round(cpu_s / args.steps * 1e3, 1),
                    "host_cores_per_rank": len(pinned) if pinned else len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                   "options": args.set_option or None,
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (
                        f" + RCCL all-gather of the decoded frames ({'uint8 video bytes' if gather_u8 else 'fp32'})" if world > 1 else "")},
     }

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhallo_amd.so")
-SOURCES = ["gemm.hip", "gemm3.hip", "gemm_rs.hip", "gemm_rs2.hip", "gemm_ff.hip", "attention.hip", "attention40.hip", "fp8.hip", "fused_xattn.hip", "norm_elementwise.hip", "wav2vec.hip"]
+SOURCES = ["gemm.hip", "gemm3.hip", "gemm4.hip", "gemm_rs.hip", "gemm_rs2.hip", "gemm_ff.hip", "attention.hip", "attention40.hip", "fp8.hip", "fused_xattn.hip", "norm_elementwise.hip", "wav2vec.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_args.h"), os.path.join(CSRC, "attn_args.h"), os.path.join(HERE, "..", "include", "hallo_amd.h")]
 
 

@@ -782,6 +782,8 @@ static int g_v3_min_tiles = 192; // auto: smallest grid (workgroups, 1 per CU) w
 // 1000 * LNF (gemm2: 0 none, 1 in-loop LayerNorm statistics, 2 external) + 100 * kernel (1 gemm_kernel, 2 gemm2_kernel,
 // 3 gemm3_kernel) + 10 * mode (0 gemm, 1 conv, 2 geglu) + stages / TM (+ 4 for the persistent gemm3 mode)
 static int g_last_kernel = 0;
+static int g_gemm4 = 1;          // hallo_set_option("gemm4", 0 off | 1 auto rule | 2 every problem gemm4.hip covers): exact-fit / stream-K kernel
+static int g_last_splits = 1;    // hallo_get_option("last_gemm_splits"): split-K factor of the last launch (gemm4: 1000 + parts of a tail tile, 1 = none)
 static int g_gemm_rs = 2;        // hallo_set_option("gemm_rs", 0 | 1 | 2): row-stationary kernels for eligible K = 320 / 640 shapes (1: gemm_rs.hip only, 2: gemm_rs2.hip at K = 320)
 
 
@@ -802,6 +804,35 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     g_last_kernel = 400 + (geglu ? 20 : 0) + (a.K == 320 ? 1 : 2) + (lnf ? 1000 : 0);
     return launch_gemm_rs<T>(a, geglu, st);
   }
+  g_last_splits = 1;
+  // ---- gemm4.hip: 128 x 160 tiles, one persistent workgroup per CU, stream-K tail (mid-size problems of the 32x32 ... 8x8 levels) ----
+  if (g_gemm4 && v >= 3 && !conv && !geglu && !gelu && batch == 1 && a.vec_ok && !a.bias_per_row && a.act <= ACT_RELU && ws &&
+      (!lnf || (a.ln_stats != nullptr && !(reinterpret_cast<uintptr_t>(a.ln_colsum) & 15) && !(a.N & 7)))) {
+    G4Sched gs;
+    // the last 64 KB of the workspace hold the arrival counters (zero between launches): split-K slabs stay below them
+    if (gemm4_plan(a, ws_bytes, &gs)) {
+      const int t4 = gs.tiles_m * gs.tiles_n;
+      // Auto rule, from tools/cbench/g4.sh (hot, per shape against the kernels it replaces: profiles/r4_gemm4_ab.txt) AND an end-to-end
+      // A/B on one box (bench.py --set-option gemm4=0 against the rule "every one-round problem with K >= 1280":
+      // 13.92 against 13.81 frames/s, profiles/r4_gemm4_e2e_ab.json).  Hot, the kernel wins where its tiles fill the chip in ONE round:
+      // 4096 x 1280 x 5120 + residual 63 us against 82 (gemm3 split 4 + reduce), 4096 x 1280 x 1280 (+ residual) 21-23 against 25.
+      // Inside the step (operands and residual cold) only the long-K case keeps its margin (74 against 87 us); at K = 1280 one
+      // workgroup per CU exposes the cold prologue, the residual round trip and the store drain that the 128x128 kernel's
+      // co-resident workgroups hide (37 against 35 us).  With two and more rounds per workgroup (4096 x 3840 x 1280: 65 against 61
+      // hot) the exposed epilogues cost more than the quantisation they remove, and a K-split tail loses to the partly filled
+      // round it replaces.  So: one round, K >= 2560.
+      const bool one_round = (gs.dp == 1 && gs.R == 0) || (gs.dp == 0 && gs.parts == 1 && t4 >= 192);
+      const bool take = g_gemm4 == 2 || (one_round && nk >= 40 && a.N % 160 == 0);
+      if (take) {
+        g_last_kernel = 600 + (lnf ? 2000 : 0);
+        g_last_splits = gs.parts > 1 ? 1000 + gs.parts : 1;
+        launch_gemm4<T>(a, gs, ws, ws_bytes, st);
+        HALLO_CHECK_LAUNCH();
+        return 0;
+      }
+    }
+  }
+  if (ws_bytes > 65536) ws_bytes -= 65536;      // (the counters of gemm4.hip)
   if (gelu) {
     if (conv || geglu || lnf) return -22;
     if (v >= 4) v = 3;
@@ -872,6 +903,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
         a.splits = (nk + a.nk_per_split - 1) / a.nk_per_split;
         a.slab = reinterpret_cast<float*>(ws);
       }
+      g_last_splits = a.splits;
       g_last_kernel = 300 + 10 * (geglu ? 2 : (conv ? 1 : 0)) + tm + (persist ? 4 : 0) + (lnf ? 2000 : 0);
       launch_gemm3<T>(a, geglu ? 2 : (conv ? 1 : 0), tm, batch, st, persist);
       HALLO_CHECK_LAUNCH();
@@ -903,6 +935,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     }
   }
   dim3 grid(tiles, a.splits, batch), block(256);
+  g_last_splits = a.splits;
   g_last_kernel = (v == 0 ? 100 : 200) + 10 * (geglu ? 2 : (conv ? 1 : (gelu && v != 0 ? 3 : 0))) + (v == 0 ? 0 : v) +
                   1000 * (v != 0 && lnf ? (a.ln_stats ? 2 : 1) : 0);
   if (v == 0) {
@@ -1033,12 +1066,16 @@ static int g_rs_dbg_value = 0;
 
 extern "C" int hallo_get_option_attn(const char* name);   // attention.hip
 
+extern "C" void hallo_gemm4_debug_buffer(long long* p) { set_gemm4_debug_buffer(p); }   // tools/cbench: s_memtime stamps of gemm4.hip
+
 extern "C" int hallo_get_option(const char* name) {
   if (!name) return -22;
   if (!strcmp(name, "gemm_variant")) return g_gemm_variant;
   if (!strcmp(name, "split_k")) return g_split_k;
   if (!strcmp(name, "v3_min_tiles")) return g_v3_min_tiles;
   if (!strcmp(name, "last_gemm_kernel")) return g_last_kernel;
+  if (!strcmp(name, "last_gemm_splits")) return g_last_splits;
+  if (!strcmp(name, "gemm4")) return g_gemm4;
   if (!strcmp(name, "gemm_rs")) return g_gemm_rs;
   if (!strcmp(name, "gemm_rs_dbg")) return g_rs_dbg_value;
   if (!strcmp(name, "ff_fused")) return ff_fused_variant();
@@ -1052,6 +1089,7 @@ extern "C" int hallo_set_option(const char* name, int value) {
   if (!strcmp(name, "conv_fast")) { if (value < 0 || value > 1) return -22; g_conv_fast = value; return 0; }
   if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }
   if (!strcmp(name, "gemm_rs")) { if (value < 0 || value > 2) return -22; g_gemm_rs = value; return 0; }
+  if (!strcmp(name, "gemm4")) { if (value < 0 || value > 2) return -22; g_gemm4 = value; return 0; }
   if (!strcmp(name, "ff_fused")) {          // 0 / 1; 2.. = A/B and timing-ablation forms of a -DHALLO_ABLATIONS build
 #ifdef HALLO_ABLATIONS
     if (value < 0 || value > 9) return -22;

@@ -52,6 +52,23 @@ bool gemm_rs2_eligible(const GemmArgs& a, bool conv, bool geglu, int batch);
 template <typename T> int launch_gemm_rs2(const GemmArgs& a, bool geglu, hipStream_t st);
 void set_gemm_rs2_dbg(int v);
 
+// gemm4.hip: exact-fit kernel for the mid-size problems (128 x 160 tiles, one persistent workgroup per CU = 4 multiplying + 4
+// loader waves, 4-slot LDS-DMA ring; the tiles of a partly filled last round may split their K loop, partial tiles reduced in K
+// order by the last arriver).  gemm4_plan() fills the schedule and says whether the kernel covers the problem (K % 64 == 0,
+// bias2 row groups >= 128 rows, vector-aligned residual); the routing rule is in launch_gemm().
+struct G4Sched {
+  int tiles_m, tiles_n, nk;   // 128 x 160 tiles, K steps of 64
+  int G;                      // persistent workgroups
+  int dp;                     // data-parallel rounds: workgroup w owns tiles xcd_remap(j * G + w), j < dp
+  int R, parts, per;          // tail: the last R tiles, each tile's K loop dealt over `parts` workgroups (`per` K steps each; parts = 1: whole tiles)
+  float* part;                // [R * parts] partial tiles (fp32 register images, 80 KB each; parts > 1)
+  int* cnt;                   // [R] arrival counters, zero between launches
+  long long* dbg;             // optional: s_memtime stamps of workgroup 0 (tools/cbench)
+};
+void set_gemm4_debug_buffer(long long* p);
+bool gemm4_plan(const GemmArgs& a, int64_t ws_bytes, G4Sched* out);
+template <typename T> int launch_gemm4(const GemmArgs& a, G4Sched s, void* ws, int64_t ws_bytes, hipStream_t st);
+
 // gemm_ff.hip: fused LayerNorm -> GEGLU -> net[2] -> + residual for C = 320 (hallo_ff320)
 int ff_fused_variant();
 void set_ff_fused_variant(int v);

@@ -76,9 +76,16 @@ def _layer(st, x, H, W, attn, audio, motion, depth):
     mf = st.cache.get(motion, "motion_frames", mf_make)
     nm = mf.shape[1]
     Ft = nm + F
-    cat = torch.empty((B, Ft, L, Cd), device=x.device, dtype=x.dtype)
+
+    # [motion frames ; clip] buffer of this layer: the motion frames are per-clip constants, so the buffer lives in the clip
+    # cache with them already in place (round 4: was a fresh buffer + a copy2d launch per layer and step); every step only
+    # rewrites the clip's rows behind them.
+    def cat_make():
+        c = torch.empty((B, Ft, L, Cd), device=x.device, dtype=x.dtype)
+        ops.copy2d(mf.view(B, nm * L * Cd), c.view(B, Ft * L * Cd), B, nm * L * Cd)
+        return c
+    cat = st.cache.get(motion, "motion_cat", cat_make)
     cat2 = cat.view(B, Ft * L * Cd)
-    ops.copy2d(mf.view(B, nm * L * Cd), cat2, B, nm * L * Cd)
     masks = st.masks[depth]
     if B == 1:
         # the audio module's output projection writes straight behind the motion frames

@@ -61,12 +61,13 @@ SPLITK_WS_BYTES = 128 << 20
 
 
 def _workspace(device):
-    """fp32 scratch for split-K partial sums: one fixed buffer per (device, stream) -- a fixed address keeps captured
-    launches replayable, and two streams never share partial sums."""
+    """fp32 scratch for split-K / stream-K partial sums: one fixed buffer per (device, stream) -- a fixed address keeps captured
+    launches replayable, and two streams never share partial sums.  ZERO-initialised: the last 64 KB hold the arrival counters
+    of the stream-K kernel (csrc/gemm4.hip), which must be zero before the first launch and are restored to zero by every launch."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _splitk_ws.get(key)
     if ws is None:
-        ws = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
+        ws = torch.zeros(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
         _splitk_ws[key] = ws
     return ws
 

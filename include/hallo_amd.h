@@ -79,7 +79,10 @@ typedef struct hallo_gemm_desc {
   int geglu;
   int out_f32;               /* write C as fp32 instead of dtype */
   int dtype;
-  void* workspace;           /* optional fp32 scratch for split-K partial sums (small grids with long K); may be null */
+  void* workspace;           /* optional fp32 scratch for split-K / stream-K partial sums (small and mid-size grids); may be null.
+                              * The caller ZERO-INITIALISES it once (hipMemset) and gives it to one stream at a time: its last
+                              * 64 KB hold the arrival counters of the stream-K kernel (csrc/gemm4.hip), zero between launches;
+                              * >= 42 MB for that kernel's stream-K tail (it is skipped with less) */
   int64_t workspace_bytes;
   /* ABI v2: output columns n < lead_cols (multiple of 8; 0 = none) are multiplied by lead_alpha on top of alpha /
    * rowscale, before the residual add.  Used for the q part of Attention.to_q / fused q|k|v projections: q leaves the

@@ -307,7 +307,12 @@ def test_gemm_big_tile_layernorm(dtype, M, Cd, geglu, report):
     wf, cs, bf = ops.fold_layernorm(gamma, beta, w, b)
     st = ops.ln_stats(x, N // 2 if geglu else N, 1e-5, geglu=geglu)
     assert st is not None                                  # K != 320: no row-stationary kernel, the caller computes the statistics
-    out = ops.gemm(x, wf, bf, geglu=geglu, ln_colsum=cs, ln_eps=1e-5, ln_stats=st)
+    g4 = ops.get_option("gemm4")
+    ops.set_option("gemm4", 0)                             # (round 4: the non-GEGLU case is gemm4.hip's by the auto rule; this test is the big tile's)
+    try:
+        out = ops.gemm(x, wf, bf, geglu=geglu, ln_colsum=cs, ln_eps=1e-5, ln_stats=st)
+    finally:
+        ops.set_option("gemm4", g4)
     code = ops.get_option("last_gemm_kernel")
     assert code // 1000 == 2 and (code % 1000) // 100 == 3, code        # 23xx: gemm3_kernel with the LayerNorm epilogue
     nh = torch.nn.functional.layer_norm(x.float(), (Cd,), gamma.float(), beta.float(), 1e-5)
@@ -383,12 +388,18 @@ def test_gemm_big_tile_cfg_and_768_row_counts(dtype, M, N, K, kind, report):
         w = _rand((N, K), dtype, g, K ** -0.5)
         b = _rand((N,), dtype, g)
         res = _rand((M, N), dtype, g)
-        out = ops.gemm(a, w, b, residual=res)
-        ref = ops_ref.linear(a, w, b) + res.float()
+        g4 = ops.get_option("gemm4")
         if kind == "res-splitk":
-            # the long-K rule of launch_gemm (csrc/gemm.hip): gemm3_kernel + fp32 slabs + the fixed-order reduce pass
-            assert (ops.get_option("last_gemm_kernel") // 100) % 10 == 3, ops.get_option("last_gemm_kernel")
-            assert torch.equal(out, ops.gemm(a, w, b, residual=res)), "split-K result is not bit-reproducible"
+            ops.set_option("gemm4", 0)      # (round 4: the 4096 x 1280 x 5120 case is gemm4.hip's by the auto rule; this test is the split big tile's)
+        try:
+            out = ops.gemm(a, w, b, residual=res)
+            ref = ops_ref.linear(a, w, b) + res.float()
+            if kind == "res-splitk":
+                # the long-K rule of launch_gemm (csrc/gemm.hip): gemm3_kernel + fp32 slabs + the fixed-order reduce pass
+                assert (ops.get_option("last_gemm_kernel") // 100) % 10 == 3, ops.get_option("last_gemm_kernel")
+                assert torch.equal(out, ops.gemm(a, w, b, residual=res)), "split-K result is not bit-reproducible"
+        finally:
+            ops.set_option("gemm4", g4)
     _check(f"gemm_rows[{M},{N},{K},{kind}]", out, ref, dtype, report)
 
 
@@ -410,3 +421,107 @@ def test_attention_l0_768_two_segment(dtype, report):
     out = ops.attention(qs, k1, v1, H, k2=k2, v2=v2, kv2_batch_div=Fr, kv2_first_batch=Fr, q_prescaled=True)
     ref = ops_ref.reference_self_attention(qs.float() / ops.q_scale(hd), k1, v1, k2, v2, H, Fr, Fr)
     _check("attn_L0_768_two_segment_cfg[40,9216,9216+9216]", out, ref, dtype, report)
+
+
+# --------------------------------------------------------------------------------------------
+# gemm4.hip (round 4): exact-fit / stream-K kernel of the 32 x 32 ... 8 x 8 levels -- 128 x 160 tiles, one persistent workgroup
+# per CU, partial tiles of the stream-K tail reduced in K order by the last arriver
+# --------------------------------------------------------------------------------------------
+G4_SHAPES = [   # M, N, K, what: every scheduling regime of the kernel
+    (4096, 1280, 1280, "res"),        # 256 tiles: exactly one per CU, no tail
+    (4096, 1280, 5120, "res"),        # the same grid, 80 K steps (ff.net[2] at 16 x 16)
+    (4096, 3840, 1280, "ln"),         # 768 tiles = 3 data-parallel rounds (q|k|v with norm1 folded in)
+    (4608, 3840, 1280, "ln"),         # 864 tiles: 3 rounds + a 96-tile stream-K tail (motion module, 18 frames)
+    (4608, 1280, 1280, "plain"),      # 288 tiles: 1 round + a 32-tile tail dealt over 256 workgroups (8 parts per tile)
+    (16384, 640, 640, "res"),         # 512 tiles, 10 K steps
+    (18432, 1920, 640, "ln"),         # 1728 tiles: 6 rounds + tail
+    (1024, 1280, 5120, "res"),        # 64 tiles < CUs: every tile's K loop shared by 4 workgroups
+    (1152, 3840, 1280, "ln"),         # 216 tiles < CUs: stream-K only
+    (1000, 1288, 1280, "res"),        # ragged: M % 128 != 0, N % 160 != 0 (N % 8 == 0)
+    (5000, 648, 704, "ln"),           # ragged with LayerNorm, 11 K steps
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,what", G4_SHAPES)
+def test_gemm4_stream_k(dtype, M, N, K, what, report):
+    """hallo_gemm on csrc/gemm4.hip (forced: hallo_set_option("gemm4", 2)) against the fp32 expression, with the residual /
+    LayerNorm epilogues of its call sites; run twice: the stream-K reduction order is fixed, the bytes must not change."""
+    from hallo_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _rand((M, K), dtype, g) * 1.1 + (0.2 if what == "ln" else 0.0)
+    w = _rand((N, K), dtype, g, K ** -0.5)
+    b = _rand((N,), dtype, g, 0.1)
+    kw = {}
+    if what == "res":
+        kw["residual"] = _rand((M, N), dtype, g)
+    g4 = ops.get_option("gemm4")
+    ops.set_option("gemm4", 2)
+    try:
+        if what == "ln":
+            gamma = (1.0 + 0.1 * torch.randn((K,), generator=g)).to(dtype).to(_dev())
+            beta = _rand((K,), dtype, g, 0.1)
+            wf, cs, bf = ops.fold_layernorm(gamma, beta, w, b)
+            st = ops.row_stats(x, 1e-5)
+            run = lambda: ops.gemm(x, wf, bf, ln_colsum=cs, ln_eps=1e-5, ln_stats=st, lead_cols=N // 3 // 8 * 8, lead_alpha=0.37)
+            nh = torch.nn.functional.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5)
+            ref = nh @ w.float().t() + b.float()
+            ref[:, :N // 3 // 8 * 8] *= 0.37
+        else:
+            run = lambda: ops.gemm(x, w, b, **kw)
+            ref = x.float() @ w.float().t() + b.float() + (kw["residual"].float() if what == "res" else 0.0)
+        out = run()
+        code = ops.get_option("last_gemm_kernel")
+        assert (code % 1000) // 100 == 6, code                 # 6xx: gemm4_kernel
+        out2 = run()
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2), "gemm4: the result changed between two runs"
+    finally:
+        ops.set_option("gemm4", g4)
+    _check(f"gemm4[{M},{N},{K},{what}]", out, ref, dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm4_epilogue_options(dtype, report):
+    """The remaining fused operations of hallo_gemm on gemm4.hip: per-frame bias2, fp32 row scale x alpha, SiLU, fp32 output, an
+    output view with a row pitch (ldc > N), and a strided A view -- on a shape with a stream-K tail."""
+    from hallo_amd import ops
+    g = torch.Generator().manual_seed(77)
+    M, N, K, rpg = 2304, 640, 1280, 256
+    abuf = _rand((M, K + 64), dtype, g)
+    x = abuf[:, 32:32 + K]                                       # row pitch K + 64, 64-byte offset
+    w = _rand((N, K), dtype, g, K ** -0.5)
+    b = _rand((N,), dtype, g, 0.1)
+    b2 = _rand((M // rpg, N), dtype, g, 0.3)
+    rs = (torch.rand((M,), generator=g) + 0.5).to(_dev())
+    res = _rand((M, N), dtype, g)
+    g4 = ops.get_option("gemm4")
+    ops.set_option("gemm4", 2)
+    try:
+        cbuf = torch.zeros((M, N + 32), device=_dev(), dtype=dtype)
+        out = ops.gemm(x, w, b, out=cbuf[:, :N], bias2=b2, bias2_rows_per_group=rpg, rowscale=rs, alpha=0.7, residual=res, act=ops.ACT_SILU)
+        assert (ops.get_option("last_gemm_kernel") % 1000) // 100 == 6
+        assert torch.count_nonzero(cbuf[:, N:]) == 0             # nothing written past the N columns of a row
+        z = (x.float() @ w.float().t() + b.float() + b2.float().repeat_interleave(rpg, 0)) * (0.7 * rs.float())[:, None] + res.float()
+        _check("gemm4_epilogue[bias2,rowscale,alpha,res,silu,ldc]", out, torch.nn.functional.silu(z), dtype, report)
+        o32 = ops.gemm(x, w, b, out_f32=True)
+        assert (ops.get_option("last_gemm_kernel") % 1000) // 100 == 6 and o32.dtype == torch.float32
+        _check("gemm4_epilogue[out_f32]", o32, x.float() @ w.float().t() + b.float(), dtype, report)
+    finally:
+        ops.set_option("gemm4", g4)
+
+
+def test_gemm4_auto_rule(report):
+    """The routing rule of launch_gemm (csrc/gemm.hip): gemm4.hip takes the one-round problems with K >= 2560 -- ff.net[2] of the
+    16 x 16 level -- and nothing else (hot and cold A/B: profiles/r4_gemm4_ab.txt, profiles/r4_gemm4_e2e_ab.json)."""
+    from hallo_amd import ops
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    took = {}
+    for (M, N, K) in ((4096, 1280, 5120), (4096, 1280, 1280), (4096, 3840, 1280), (16384, 640, 2560), (1024, 1280, 5120), (65536, 320, 1280)):
+        a, w, b = _rand((M, K), dtype, g), _rand((N, K), dtype, g, K ** -0.5), _rand((N,), dtype, g)
+        ops.gemm(a, w, b, residual=_rand((M, N), dtype, g))
+        took[(M, N, K)] = (ops.get_option("last_gemm_kernel") % 1000) // 100
+    assert took[(4096, 1280, 5120)] == 6, took
+    assert all(v != 6 for k, v in took.items() if k != (4096, 1280, 5120)), took
+    report.append({"test": "gemm4_auto_rule", "kernel_family_by_shape": {str(k): v for k, v in took.items()}})

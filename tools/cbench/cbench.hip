@@ -316,7 +316,8 @@ static int cmd_attn_nan(int argc, char** argv) {
 // ---------------------------------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------------------------------
-struct GemmOpts { int M, N, K; bool geglu = false, ln = false, res = false; int rs = -1, variant = -1, rsdbg = 0; float ascale = 1.0f, wscale = 1.0f; int dt = DT_BF16; bool check = true; };
+extern "C" void hallo_gemm4_debug_buffer(long long* p) __attribute__((weak));
+struct GemmOpts { bool stamps = false; int M, N, K; bool geglu = false, ln = false, res = false; int rs = -1, variant = -1, rsdbg = 0, g4 = -1; float ascale = 1.0f, wscale = 1.0f; int dt = DT_BF16; bool check = true; };
 
 static void run_gemm_case(const GemmOpts& g, Timer& tm) {
   const int wrows = g.geglu ? 2 * g.N : g.N, dt = g.dt;
@@ -331,6 +332,7 @@ static void run_gemm_case(const GemmOpts& g, Timer& tm) {
   if (g.ln) hipLaunchKernelGGL(fold_ln, dim3((wrows + 63) / 64), dim3(64), 0, 0, W, bias, gamma, beta, Wf, bf, cs, wrows, g.K, dt);
   if (g.rs >= 0) HK(hallo_set_option("gemm_rs", g.rs));
   if (g.variant >= 0) HK(hallo_set_option("gemm_variant", g.variant));
+  if (g.g4 >= 0) HK(hallo_set_option("gemm4", g.g4));
   HK(hallo_set_option("gemm_rs_dbg", g.rsdbg));
   hallo_gemm_desc d; memset(&d, 0, sizeof d);
   d.A = A; d.B = g.ln ? Wf : W; d.C = Cc; d.M = g.M; d.N = g.N; d.K = g.K; d.lda = g.K; d.ldb = g.K; d.ldc = g.N; d.batch = 1;
@@ -338,7 +340,7 @@ static void run_gemm_case(const GemmOpts& g, Timer& tm) {
   if (g.ln) { d.ln_colsum = cs; d.ln_eps = 1e-5f; }
   static void* ws = nullptr;                       // split-K scratch, as hallo_amd/ops.py hands one to every GEMM
   const long ws_bytes = 256L << 20;
-  if (!ws) CK(hipMalloc(&ws, ws_bytes));
+  if (!ws) { CK(hipMalloc(&ws, ws_bytes)); CK(hipMemset(ws, 0, ws_bytes)); }      // zero-initialised: the stream-K kernel's arrival counters
   d.workspace = ws; d.workspace_bytes = ws_bytes;
   const bool fused_stats = g.ln && hallo_gemm_fuses_row_stats(g.M, g.N, g.K, g.geglu, 0, 0);
   if (g.ln && !fused_stats) d.ln_stats = stats;
@@ -346,9 +348,32 @@ static void run_gemm_case(const GemmOpts& g, Timer& tm) {
     if (g.ln && !fused_stats) HK(hallo_row_stats(A, stats, g.M, g.K, 1e-5f, dt, nullptr));
     HK(hallo_gemm(&d, nullptr));
   };
+  // g4 > 0: the same problem on the kernels it replaces first (gemm4 = 0), for a FULL-matrix comparison of the stream-K kernel
+  std::vector<uint16_t> base_out;
+  int base_kern = 0;
+  if (g.g4 > 0) {
+    HK(hallo_set_option("gemm4", 0));
+    launch(); CK(hipDeviceSynchronize());
+    base_kern = hallo_get_option("last_gemm_kernel");
+    base_out.resize((long)g.M * g.N);
+    CK(hipMemcpy(base_out.data(), Cc, base_out.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemset(Cc, 0xFF, (long)g.M * g.N * 2));
+    HK(hallo_set_option("gemm4", g.g4));
+  }
   launch(); CK(hipDeviceSynchronize());
   const int kern = hallo_get_option("last_gemm_kernel");
   double rel = -1; long nan = 0; int nondet = 0;
+  if (!base_out.empty()) {
+    std::vector<uint16_t> o4((long)g.M * g.N);
+    CK(hipMemcpy(o4.data(), Cc, o4.size() * 2, hipMemcpyDeviceToHost));
+    double en = 0, rn = 0, mx = 0; long differ = 0, bad = 0;
+    for (long i = 0; i < (long)g.M * g.N; ++i) {
+      const float x = host_to_f(o4[i], dt), y = host_to_f(base_out[i], dt);
+      if (x != x) ++bad;
+      const double e = (double)x - y; en += e * e; rn += (double)y * y; if (fabs(e) > mx) mx = fabs(e); if (o4[i] != base_out[i]) ++differ;
+    }
+    printf("  full matrix vs kernel %d: rel_l2=%.3e max_abs=%.3e elements differing=%ld of %ld nan=%ld\n", base_kern, sqrt(en / rn), mx, differ, (long)g.M * g.N, bad);
+  }
   if (g.check) {
     const int rows = std::min(g.M, 512);
     float* ref = dalloc<float>((long)rows * g.N);
@@ -372,14 +397,29 @@ static void run_gemm_case(const GemmOpts& g, Timer& tm) {
   std::vector<float> t; for (int r = 0; r < g_rounds; ++r) t.push_back(tm.run(launch, g_iters));
   const float us = median(t);
   const double flop = 2.0 * g.M * (double)wrows * g.K, bytes = 2.0 * ((double)g.M * g.K + (double)wrows * g.K + (double)g.M * g.N * (g.res ? 2 : 1));
-  printf("gemm M=%d N=%d K=%d%s%s%s dt=%s rs=%d variant=%d rsdbg=%d kernel=%d fused_stats=%d: %.1f us  %.1f TFLOP/s  %.0f GB/s  rel_l2(first rows)=%.2e nan=%ld nondet=%d\n",
-         g.M, g.N, g.K, g.geglu ? " geglu" : "", g.ln ? " ln" : "", g.res ? " res" : "", dt ? "bf16" : "f16", g.rs, g.variant, g.rsdbg, kern, (int)fused_stats,
+  printf("gemm M=%d N=%d K=%d%s%s%s dt=%s rs=%d variant=%d g4=%d rsdbg=%d kernel=%d splits=%d fused_stats=%d: %.1f us  %.1f TFLOP/s  %.0f GB/s  rel_l2(first rows)=%.2e nan=%ld nondet=%d\n",
+         g.M, g.N, g.K, g.geglu ? " geglu" : "", g.ln ? " ln" : "", g.res ? " res" : "", dt ? "bf16" : "f16", g.rs, g.variant, g.g4, g.rsdbg, kern, hallo_get_option("last_gemm_splits"), (int)fused_stats,
          us, flop / us / 1e6, bytes / us / 1e3, rel, nan, nondet);
+  if (g.stamps && hallo_gemm4_debug_buffer) {
+    // s_memtime stamps of workgroup 0 / wave 0 of gemm4.hip (100 MHz constant clock on gfx950: 1 tick = 10 ns): [0] start, [1] first
+    // K step visible, [2 + k] end of K step k (k < 24), [30] K loop done, [31] epilogue done
+    long long* dbg = dalloc<long long>(64); CK(hipMemset(dbg, 0, 64 * 8));
+    hallo_gemm4_debug_buffer(dbg);
+    launch(); CK(hipDeviceSynchronize());
+    hallo_gemm4_debug_buffer(nullptr);
+    long long h[64]; CK(hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
+    printf("  stamps (ticks from start): first step visible %lld |", h[1] - h[0]);
+    for (int k = 0; k < 24 && h[2 + k]; ++k) printf(" %lld", h[2 + k] - h[0]);
+    printf(" | loop done %lld | epilogue: constants + residual loads issued %lld, 16-row blocks done %lld %lld %lld %lld | epilogue done %lld\n", h[30] - h[0],
+           h[32] - h[0], h[33] - h[0], h[34] - h[0], h[35] - h[0], h[36] - h[0], h[31] - h[0]);
+    CK(hipFree(dbg));
+  }
   fflush(stdout);
   CK(hipFree(A)); CK(hipFree(W)); CK(hipFree(Wf)); CK(hipFree(bias)); CK(hipFree(bf)); CK(hipFree(gamma)); CK(hipFree(beta)); CK(hipFree(cs));
   CK(hipFree(Cc)); if (R) CK(hipFree(R)); CK(hipFree(stats));
   if (g.rs >= 0) HK(hallo_set_option("gemm_rs", 1));
   if (g.variant >= 0) HK(hallo_set_option("gemm_variant", 6));
+  if (g.g4 >= 0) HK(hallo_set_option("gemm4", 1));
   HK(hallo_set_option("gemm_rs_dbg", 0));
 }
 
@@ -388,7 +428,7 @@ static GemmOpts parse_gemm(int argc, char** argv) {
   for (int i = 3; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "geglu") g.geglu = true; else if (a == "ln") g.ln = true; else if (a == "res") g.res = true; else if (a == "nocheck") g.check = false;
-    else if (a == "f16") g.dt = DT_F16; else if (a.rfind("rs=", 0) == 0) g.rs = atoi(a.c_str() + 3); else if (a.rfind("variant=", 0) == 0) g.variant = atoi(a.c_str() + 8);
+    else if (a == "f16") g.dt = DT_F16; else if (a.rfind("rs=", 0) == 0) g.rs = atoi(a.c_str() + 3); else if (a.rfind("variant=", 0) == 0) g.variant = atoi(a.c_str() + 8); else if (a.rfind("g4=", 0) == 0) g.g4 = atoi(a.c_str() + 3); else if (a == "stamps") g.stamps = true;
     else if (a == "zeroA") { g.ascale = 0.0f; g.check = false; } else if (a == "zeroW") { g.wscale = 0.0f; g.check = false; }
     else if (a.rfind("rsdbg=", 0) == 0) { g.rsdbg = atoi(a.c_str() + 6); if (g.rsdbg) g.check = false; }
   }
@@ -467,7 +507,7 @@ static int cmd_ff(int argc, char** argv) {
   std::vector<uint8_t> img = ff_pack(hw1, hb1, hw2, dt);
   if ((int64_t)img.size() != hallo_ff320_pack_bytes()) { fprintf(stderr, "pack size mismatch\n"); return 4; }
   uint8_t* dimg = dalloc<uint8_t>(img.size()); CK(hipMemcpy(dimg, img.data(), img.size(), hipMemcpyHostToDevice));
-  static void* ws = nullptr; const long ws_bytes = 256L << 20; if (!ws) CK(hipMalloc(&ws, ws_bytes));
+  static void* ws = nullptr; const long ws_bytes = 256L << 20; if (!ws) { CK(hipMalloc(&ws, ws_bytes)); CK(hipMemset(ws, 0, ws_bytes)); }
   // the two-GEMM path
   hallo_gemm_desc d1; memset(&d1, 0, sizeof d1);
   d1.A = X; d1.B = W1f; d1.C = Hb; d1.M = M; d1.N = I; d1.K = C; d1.lda = C; d1.ldb = C; d1.ldc = I; d1.batch = 1; d1.bias = b1f; d1.alpha = 1.0f;
