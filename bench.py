@@ -7,7 +7,12 @@ on synthetic inputs already resident in HBM: face tokens + VAE-encode(3) + FaceL
 + 25 x (UNet3D, B=1, no CFG) + fused DDIM + batched VAE decode(16) + D2H of the fp32 frames; for N > 1 one
 RCCL all-gather of the decoded frames per wave of clips (BASELINE.json configs[3]'s exchange).
 A "step" = one clip per rank.  bf16 storage, fp32 accumulation, random-init weights of the reference
-architecture, synthetic inputs.
+architecture, synthetic inputs.  The K timed clips of a rank are independent (each carries its own reference / motion
+frames, the clip-parallel contract of DESIGN section 8) and are issued back to back over `--inflight` (default 3) pipeline
+objects + HIP streams sharing the weights, so that up to three clips overlap on the GPU (+11 % frames/s over one clip at a
+time: the 16x16 / 8x8 levels and the tail of every launch leave CUs idle that another clip's kernels fill); frames are
+byte-identical to one-at-a-time execution (tests/test_models_gpu.py::test_pipeline_clips_in_flight_are_byte_identical).
+`ms_per_step` = timed wall time / K (throughput); `clip_latency_ms` = that x clips in flight.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -312,8 +317,8 @@ def cpu_baseline(frames, steps_ddim, budget_s=150.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2, help="timed clips per rank")
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6, help="timed clips per rank")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--ddim-steps", type=int, default=25)
@@ -324,6 +329,11 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds of host time the CPU baseline may use")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B: hallo_set_option('gemm_variant', v) (default: library auto)")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="clips in flight per GPU: consecutive clips alternate over this many (pipeline object, HIP stream) pairs that share "
+                         "the weights, so that one clip's low-occupancy phases (16x16 / 8x8 levels, tails of every launch) are filled by "
+                         "another clip's kernels.  Throughput metric: the K timed clips are the same work, issued back to back.  Same box, "
+                         "same binary: 16.08 frames/s with 1, 17.7 with 2, 17.9 with 3 or 4, 17.6 with 6 (profiles/r4_inflight_ab.json)")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: hallo_set_option(NAME, VALUE) before the pipeline is built (e.g. gemm4=0); recorded in config.options")
     ap.add_argument("--shape-breakdown", action="store_true", help="write gpurun_out/shape_breakdown.json (per op x shape times)")
@@ -412,15 +422,24 @@ def main():
         # tests/test_multigpu_gpu.py::test_graph_replay_next_to_rccl_world1; should the capture fail on a multi-GPU node anyway,
         # the warm-up below falls back to eager launches and the JSON line says so.
         pipe.use_graph = not args.no_graph and args.warmup > 0
+        # --inflight n: n pipeline objects over the same networks (own scheduler, own captured graph + static buffers), one HIP stream each
+        from hallo_amd.animate.face_animate import FaceAnimatePipeline as _FAP
+        from hallo_amd.synthetic import make_scheduler as _mk
+        pipes = [pipe] + [_FAP(vae=pipe.vae, reference_unet=pipe.reference_unet, denoising_unet=pipe.denoising_unet,
+                               face_locator=pipe.face_locator, image_proj=pipe.image_proj, scheduler=_mk(), use_graph=pipe.use_graph)
+                          for _ in range(max(1, args.inflight) - 1)]
+        streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(len(pipes) - 1)]
     from hallo_amd.animate.clip_parallel import gather_wave
     gather_u8 = world > 1 and (args.gather or ("f32" if dry else "u8")) == "u8"
     # rank 0 receives the whole wave (one clip per rank) and copies ALL of it to the host
+    n_slots = 1 if dry else len(pipes)
     if gather_u8:
-        host = torch.empty((world if rank == 0 else 1, Fr, S * S, 3), dtype=torch.uint8)
+        hosts = [torch.empty((world if rank == 0 else 1, Fr, S * S, 3), dtype=torch.uint8) for _ in range(n_slots)]
     else:
-        host = torch.empty((world if rank == 0 else 1, Fr, 3, S * S), dtype=torch.float32)
+        hosts = [torch.empty((world if rank == 0 else 1, Fr, 3, S * S), dtype=torch.float32) for _ in range(n_slots)]
     if not dry:
-        host = host.pin_memory()
+        hosts = [h_.pin_memory() for h_ in hosts]
+    host = hosts[0]
 
     def one_clip(idx):
         if dry:
@@ -429,7 +448,13 @@ def main():
         sync()
         return d
 
-    def run(d, exchange=True):
+    def run(d, exchange=True, slot=0):
+        if not dry and len(pipes) > 1:
+            with torch.cuda.stream(streams[slot]):
+                return run_on(d, exchange, pipes[slot], hosts[slot])
+        return run_on(d, exchange, None if dry else pipes[slot], hosts[slot])
+
+    def run_on(d, exchange, pipe, host):
         if dry:
             frames = torch.full((Fr, 3, S * S), d["stub"])
         else:
@@ -453,25 +478,30 @@ def main():
 
     inputs = [one_clip(i) for i in range(args.warmup + args.steps)]
     graph_note = None
-    for i in range(args.warmup):
+    if not dry and len(pipes) > 1:
+        for st_ in streams[1:]:
+            st_.wait_stream(streams[0])              # the synthetic inputs were produced on the default stream
+    for i in range(max(args.warmup, 0 if dry else (len(pipes) if args.warmup > 0 else 0))):
         try:
-            run(inputs[i])
+            run(inputs[i % len(inputs)], slot=i % n_slots)     # every (pipeline, stream) pair captures its graph in the warm-up
         except Exception as e:          # a failed capture must not cost the measurement: eager launches, and say so
             if dry or not pipe.use_graph:
                 raise
             graph_note = f"eager (hipGraph capture failed in the warm-up: {type(e).__name__}: {str(e)[:160]})"
-            pipe.use_graph = False
-            pipe.reset_graphs()
+            for p_ in pipes:
+                p_.use_graph = False
+                p_.reset_graphs()
             sync()
-            run(inputs[i])
+            run(inputs[i % len(inputs)], slot=i % n_slots)
     if world > 1 and not dry:
         # every rank must take the same launch path: if one rank's capture failed, all go eager
         flag = torch.tensor([0 if pipe.use_graph else 1], device=dev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()) and pipe.use_graph:
             graph_note = graph_note or "eager (another rank's hipGraph capture failed in the warm-up)"
-            pipe.use_graph = False
-            pipe.reset_graphs()
+            for p_ in pipes:
+                p_.use_graph = False
+                p_.reset_graphs()
 
     def fence():
         sync()
@@ -484,7 +514,7 @@ def main():
     cpu0 = time.process_time()
     for i in range(args.steps):
         th = time.perf_counter()
-        run(inputs[args.warmup + i])
+        run(inputs[args.warmup + i], slot=i % n_slots)
         host_s += time.perf_counter() - th      # wall time inside the enqueue calls of a clip: includes the runtime's back-pressure
     cpu_s = time.process_time() - cpu0          # when the hardware queue is full (25 replays x ~690 packets); CPU time of the process
     fence()
@@ -507,7 +537,7 @@ def main():
     out = {
         "metric": "generated frames/sec at 512x512, 16-frame window, 25 DDIM steps",
         "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": elapsed / args.steps * 1e3, "clip_latency_ms": elapsed / args.steps * 1e3 * n_slots, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype + ("+fp8proj" if args.fp8_proj else ""), "data": "synthetic (random-init weights of the reference architecture, synthetic clip inputs)",
         "config": {"workload": f"{cfg_name} per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
                                f"steps, guidance {args.guidance} ({'CFG, B=2' if args.guidance > 1 else 'no CFG, B=1'}), "
@@ -517,6 +547,8 @@ def main():
                    "host_cpu_ms_per_clip": round(cpu_s / args.steps * 1e3, 1),
                    "host_cores_per_rank": len(pinned) if pinned else len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                    "options": args.set_option or None,
+                   "clips_in_flight_per_gpu": n_slots,
+                   "warmup_clips_run": max(args.warmup, n_slots if args.warmup > 0 else 0),
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (
                        f" + RCCL all-gather of the decoded frames ({'uint8 video bytes' if gather_u8 else 'fp32'})" if world > 1 else "")},
     }

@@ -63,11 +63,13 @@ SPLITK_WS_BYTES = 128 << 20
 def _workspace(device):
     """fp32 scratch for split-K / stream-K partial sums: one fixed buffer per (device, stream) -- a fixed address keeps captured
     launches replayable, and two streams never share partial sums.  ZERO-initialised: the last 64 KB hold the arrival counters
-    of the stream-K kernel (csrc/gemm4.hip), which must be zero before the first launch and are restored to zero by every launch."""
+    of csrc/gemm4.hip's K-split tail, which must be zero before the first launch and are restored to zero by every launch (the
+    slab / partial-tile area below them needs no initialisation)."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _splitk_ws.get(key)
     if ws is None:
-        ws = torch.zeros(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
+        ws = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
+        ws[-(65536 // 4):].zero_()          # the counters only: a workspace first seen inside a graph capture re-zeroes 64 KB per replay, not 128 MB
         _splitk_ws[key] = ws
     return ws
 
@@ -384,22 +386,33 @@ def face_xattn(x, sg, g, b, owp, bo, rows_per_batch, eps, out=None):
 
 
 def face_xattn_constants(wq, kf, vf, wo, gamma, beta, heads, dtype):
-    """Per-clip constant folding for face_xattn (fp32 torch math on a handful of [32, C] matrices, once per clip and
-    block).  wq [C, C] (to_q.weight), wo [C, C] (to_out[0].weight), kf / vf [nb, T, C] projected face tokens
-    (heads * T must be 32), gamma / beta [C] of norm2."""
+    """Per-clip constant folding for face_xattn (once per clip and block).  wq [C, C] (to_q.weight), wo [C, C]
+    (to_out[0].weight), kf / vf [nb, T, C] projected face tokens (heads * T must be 32), gamma / beta [C] of norm2.
+    The two contractions over the head dimension run on hallo_gemm (strided-batched over the heads, fp32 output: round 4 -- they
+    were torch.einsum calls, i.e. rocBLAS / Tensile kernels on the timed path); what is left to torch is elementwise work on
+    [nb, 32, C] fp32 matrices."""
     nb, T, Cd = kf.shape
     hd = Cd // heads
     assert T == 4 and heads <= 8, "the fused kernel covers 8 heads x 4 tokens (fewer heads are zero-padded)"
     f = lambda t: t.float()
     HT = heads * T
+
+    def per_head(tok, w_rows):
+        """out[b, h*T + t, c] = sum_d tok[b, t, h*hd + d] * w_rows[c, h*hd + d]: batch = heads, A [nb*T, hd] (row pitch C), W [C, hd]"""
+        a = tok.reshape(nb * T, Cd).view(nb * T, heads, hd).permute(1, 0, 2)
+        w = w_rows.view(Cd, heads, hd).permute(1, 0, 2)
+        out = torch.empty((heads, nb * T, Cd), device=tok.device, dtype=torch.float32)
+        gemm_batched(a, w, out, out_f32=True)
+        return out.view(heads, nb, T, Cd).permute(1, 0, 2, 3).reshape(nb, HT, Cd)
+
     sw = torch.zeros((nb, 32, Cd), device=kf.device, dtype=torch.float32)
-    sw[:, :HT] = torch.einsum("bthd,hdc->bhtc", f(kf).view(nb, T, heads, hd), f(wq).view(heads, hd, Cd)).reshape(nb, HT, Cd)
+    sw[:, :HT] = per_head(kf.contiguous(), wq.t().contiguous())           # sum_d K[b,t,h,d] * Wq[(h d), c]
     sw = sw * q_scale(hd)
     sg = (sw * f(gamma)).to(dtype).contiguous()
     g = sg.float().sum(-1).contiguous()                                   # from the ROUNDED sg: the kernel multiplies x by it
     b = (sw * f(beta)).sum(-1).contiguous()
     ow = torch.zeros((nb, 32, Cd), device=kf.device, dtype=torch.float32)  # padded heads: uniform p times zero rows
-    ow[:, :HT] = torch.einsum("bthd,chd->bhtc", f(vf).view(nb, T, heads, hd), f(wo).view(Cd, heads, hd)).reshape(nb, HT, Cd)
+    ow[:, :HT] = per_head(vf.contiguous(), wo.contiguous())               # sum_d V[b,t,h,d] * Wo[c, (h d)]
     # k-slot order of the second MFMA: slot (ks2, hi, e) <-> (h,t) = 8*(2*ks2 + (e >> 2)) + 4*hi + (e & 3)
     ks2, hi, e = torch.meshgrid(torch.arange(2), torch.arange(2), torch.arange(8), indexing="ij")
     j = (8 * (2 * ks2 + (e >> 2)) + 4 * hi + (e & 3)).reshape(-1).to(ow.device)

@@ -253,6 +253,53 @@ def test_pipeline_hipgraph_survives_reload_and_option_change(nets, report):
     report.append({"test": "pipeline_hipgraph_reload_and_option_change", "dtype": str(dtype), "byte_identical": True})
 
 
+def test_pipeline_clips_in_flight_are_byte_identical(nets, report):
+    """bench.py --inflight n (round 4): consecutive independent clips alternate over n (FaceAnimatePipeline, HIP stream) pairs that
+    share the networks, so that two or three clips overlap on the GPU.  Shared state must be read-only while clips overlap: every
+    clip's frames must equal, byte for byte, the frames of the same clip run alone on one pipeline -- with graph replay (each
+    pair captures its own graph) and with eager launches."""
+    dtype, o, n = nets
+    from oracle import harness as Hn
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.scheduler import DDIMScheduler
+    S, Fr, steps, slots, clips = 128, 4, 4, 3, 6
+    mk = lambda: DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                               prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    kw = dict(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+              face_locator=n["face_locator"], image_proj=n["imageproj"])
+    rd = lambda t: t.to(dtype).float()
+    dev = torch.device("cuda:0")
+
+    def inputs(i):
+        d = Hn.clip_inputs(S, Fr, seed=1234 + i)
+        lat = rd(torch.randn(d["latents"].shape, generator=torch.Generator().manual_seed(42 + i)))
+        args = (rd(d["ref_image"]).to(dev), rd(d["face_emb"]).to(dev), rd(d["audio"]).to(dev), d["face_mask"].to(dev),
+                [rd(m).to(dev) for m in d["full"]], [rd(m).to(dev) for m in d["face"]], [rd(m).to(dev) for m in d["lip"]], S, S, Fr, steps, 1.0)
+        return args, lat.to(dev)
+    ins = [inputs(i) for i in range(clips)]
+    alone = FaceAnimatePipeline(scheduler=mk(), **kw)
+    ref = [alone(*a, motion_scale=[1.0, 0.8, 1.2], latents=l, output_type="device").videos.clone() for a, l in ins]
+    torch.cuda.synchronize()
+    for graph in (True, False):
+        pipes = [FaceAnimatePipeline(scheduler=mk(), use_graph=graph, **kw) for _ in range(slots)]
+        streams = [torch.cuda.Stream(dev) for _ in range(slots)]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream(dev))
+        got = []
+        for rnd in range(2):                  # round 0 captures the graphs, round 1 replays them from the first step on
+            got = []
+            for i, (a, l) in enumerate(ins):
+                with torch.cuda.stream(streams[i % slots]):
+                    got.append(pipes[i % slots](*a, motion_scale=[1.0, 0.8, 1.2], latents=l, output_type="device").videos)
+            torch.cuda.synchronize()
+            for i in range(clips):
+                assert torch.equal(got[i], ref[i]), (graph, rnd, i, (got[i] - ref[i]).abs().max().item())
+        for p_ in pipes:
+            p_.reset_graphs()
+    assert not torch.equal(ref[0], ref[1])
+    report.append({"test": "pipeline_clips_in_flight_byte_identical", "dtype": str(dtype), "slots": slots, "clips": clips})
+
+
 # ------------------------------------------------------------------------------------------------
 # SURVEY 8f rows 1 + 3: the sliding-window driver (motion-frame carry on the device, shared generator stream)
 # and the uint8 output conversion
