@@ -334,6 +334,7 @@ def main():
                          "the weights, so that one clip's low-occupancy phases (16x16 / 8x8 levels, tails of every launch) are filled by "
                          "another clip's kernels.  Throughput metric: the K timed clips are the same work, issued back to back.  Same box, "
                          "same binary: 16.08 frames/s with 1, 17.7 with 2, 17.9 with 3 or 4, 17.6 with 6 (profiles/r4_inflight_ab.json)")
+    ap.add_argument("--no-slot-wait", action="store_true", help="A/B: do not wait (blocking event) for a slot's previous clip before enqueuing its next one")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: hallo_set_option(NAME, VALUE) before the pipeline is built (e.g. gemm4=0); recorded in config.options")
     ap.add_argument("--shape-breakdown", action="store_true", help="write gpurun_out/shape_breakdown.json (per op x shape times)")
@@ -448,10 +449,21 @@ def main():
         sync()
         return d
 
+    # A slot's next clip is enqueued only once its previous clip has finished, waited for with a BLOCKING event (the host thread
+    # sleeps instead of spinning inside a launch call against a full hardware queue: with 8 ranks sharing one host that is 8 cores
+    # given back); the clips of the other slots keep the GPU busy meanwhile.
+    slot_done = [None] * (1 if dry else len(pipes))
+
     def run(d, exchange=True, slot=0):
         if not dry and len(pipes) > 1:
+            if slot_done[slot] is not None and not args.no_slot_wait:
+                slot_done[slot].synchronize()
             with torch.cuda.stream(streams[slot]):
-                return run_on(d, exchange, pipes[slot], hosts[slot])
+                r_ = run_on(d, exchange, pipes[slot], hosts[slot])
+                if slot_done[slot] is None:
+                    slot_done[slot] = torch.cuda.Event(blocking=True)
+                slot_done[slot].record(streams[slot])
+                return r_
         return run_on(d, exchange, None if dry else pipes[slot], hosts[slot])
 
     def run_on(d, exchange, pipe, host):
@@ -588,17 +600,18 @@ def main():
                                  for k, d in sorted(prof.by_symbol.items(), key=lambda kv: -kv[1]["ms"])[:12]}
         name, d = max(prof.by_symbol.items(), key=lambda kv: kv[1]["ms"])
         # HBM traffic of the dominant symbol from separate rocprofv3 --pmc passes (tools/cbench/pmc.sh + tools/
-        # pmc_traffic_cbench.py -> profiles/r3_pmc_traffic.json): FETCH_SIZE / WRITE_SIZE of single launches next to the
+        # pmc_traffic_cbench.py -> profiles/r4_pmc_traffic.json): FETCH_SIZE / WRITE_SIZE of single launches next to the
         # algorithmic bytes of THOSE launches, per launch shape.  It is a committed measurement of this binary's kernel, not
         # something this run produced (the counter passes cannot run inside a timed bench).
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))
+            tpath = next(pp for pp in (os.path.join(ROOT, "profiles", f) for f in ("r4_pmc_traffic.json", "r3_pmc_traffic.json")) if os.path.exists(pp))
+            tj = json.load(open(tpath))
             t = tj.get(name.split("<")[0])
             if t:
                 traffic = {"per_launch_shape": [{k: (round(v) if isinstance(v, float) and v > 1000 else v) for k, v in e.items()} for e in t],
                            "algorithmic_bytes_per_launch_this_run": round(d["bytes"] / d["launches"]),
-                           "source": "profiles/r3_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT+MISS, one counter group "
+                           "source": os.path.basename(tpath) + " (profiles/): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT+MISS, one counter group "
                                      "per pass over tools/cbench launches of this kernel at these shapes (tools/cbench/pmc.sh, tools/"
                                      "pmc_traffic_cbench.py; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md).  A committed measurement of "
                                      "this binary's kernel, not produced by this run"}

@@ -782,6 +782,7 @@ static int g_v3_min_tiles = 192; // auto: smallest grid (workgroups, 1 per CU) w
 // 1000 * LNF (gemm2: 0 none, 1 in-loop LayerNorm statistics, 2 external) + 100 * kernel (1 gemm_kernel, 2 gemm2_kernel,
 // 3 gemm3_kernel) + 10 * mode (0 gemm, 1 conv, 2 geglu) + stages / TM (+ 4 for the persistent gemm3 mode)
 static int g_last_kernel = 0;
+static int g_gemm4_min_nk = 40;  // hallo_set_option("gemm4_min_nk", n): shortest K loop (64-deep steps) the auto rule gives to gemm4.hip (A/B)
 static int g_gemm4 = 1;          // hallo_set_option("gemm4", 0 off | 1 auto rule | 2 every problem gemm4.hip covers): exact-fit / stream-K kernel
 static int g_last_splits = 1;    // hallo_get_option("last_gemm_splits"): split-K factor of the last launch (gemm4: 1000 + parts of a tail tile, 1 = none)
 static int g_gemm_rs = 2;        // hallo_set_option("gemm_rs", 0 | 1 | 2): row-stationary kernels for eligible K = 320 / 640 shapes (1: gemm_rs.hip only, 2: gemm_rs2.hip at K = 320)
@@ -822,7 +823,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
       // hot) the exposed epilogues cost more than the quantisation they remove, and a K-split tail loses to the partly filled
       // round it replaces.  So: one round, K >= 2560.
       const bool one_round = (gs.dp == 1 && gs.R == 0) || (gs.dp == 0 && gs.parts == 1 && t4 >= 192);
-      const bool take = g_gemm4 == 2 || (one_round && nk >= 40 && a.N % 160 == 0);
+      const bool take = g_gemm4 == 2 || (one_round && nk >= g_gemm4_min_nk && a.N % 160 == 0);
       if (take) {
         g_last_kernel = 600 + (lnf ? 2000 : 0);
         g_last_splits = gs.parts > 1 ? 1000 + gs.parts : 1;
@@ -1076,6 +1077,7 @@ extern "C" int hallo_get_option(const char* name) {
   if (!strcmp(name, "last_gemm_kernel")) return g_last_kernel;
   if (!strcmp(name, "last_gemm_splits")) return g_last_splits;
   if (!strcmp(name, "gemm4")) return g_gemm4;
+  if (!strcmp(name, "gemm4_min_nk")) return g_gemm4_min_nk;
   if (!strcmp(name, "gemm_rs")) return g_gemm_rs;
   if (!strcmp(name, "gemm_rs_dbg")) return g_rs_dbg_value;
   if (!strcmp(name, "ff_fused")) return ff_fused_variant();
@@ -1090,6 +1092,7 @@ extern "C" int hallo_set_option(const char* name, int value) {
   if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }
   if (!strcmp(name, "gemm_rs")) { if (value < 0 || value > 2) return -22; g_gemm_rs = value; return 0; }
   if (!strcmp(name, "gemm4")) { if (value < 0 || value > 2) return -22; g_gemm4 = value; return 0; }
+  if (!strcmp(name, "gemm4_min_nk")) { if (value < 4) return -22; g_gemm4_min_nk = value; return 0; }
   if (!strcmp(name, "ff_fused")) {          // 0 / 1; 2.. = A/B and timing-ablation forms of a -DHALLO_ABLATIONS build
 #ifdef HALLO_ABLATIONS
     if (value < 0 || value > 9) return -22;

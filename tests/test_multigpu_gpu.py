@@ -77,9 +77,10 @@ def test_two_gpus_byte_identical_to_one(tmp_path):
 
 def rccl_graph_worker(rank, world, port, out_dir):
     """One rank (world = 1 on the development boxes, any world on a node): RCCL communicator initialised FIRST (its watchdog /
-    proxy threads are alive and issue HIP calls), then two clips through FaceAnimatePipeline(use_graph=True) -- clip 1 captures
-    the UNet graph, clip 2 replays it -- each followed by gather_wave on the group, and the same two clips eagerly: the
-    gathered bytes must be identical.  This is the launch path bench.py takes at N > 1."""
+    proxy threads are alive and issue HIP calls), then four clips alternating over two (pipeline, stream) pairs with use_graph=True
+    -- each pair captures its UNet graph on its first clip and replays it -- every clip followed by gather_wave on the group from
+    its own stream, and the same four clips eagerly on one pipeline: the gathered bytes must be identical.  This is the launch
+    path bench.py takes at N > 1 (clips in flight: round 4)."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -101,24 +102,42 @@ def rccl_graph_worker(rank, world, port, out_dir):
     S, Fr, steps = 64, 2, 4
     kw = dict(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"], face_locator=n["face_locator"],
               image_proj=n["imageproj"])
-    pipes = {"graph": FaceAnimatePipeline(scheduler=make_scheduler(), use_graph=True, **kw),
-             "eager": FaceAnimatePipeline(scheduler=make_scheduler(), **kw)}
+    # "graph": what bench.py runs at N > 1 since round 4 -- TWO (pipeline, stream) pairs with a captured graph each, clips
+    # alternating over them (clips in flight), every clip's frames all-gathered from its own stream; "eager": one pipeline, one
+    # stream, launch by launch
+    slots = 2
+    gp = [FaceAnimatePipeline(scheduler=make_scheduler(), use_graph=True, **kw) for _ in range(slots)]
+    gs = [torch.cuda.Stream(dev) for _ in range(slots)]
+    for st in gs:
+        st.wait_stream(torch.cuda.current_stream(dev))
+    ep = FaceAnimatePipeline(scheduler=make_scheduler(), **kw)
+    nclips = 4
     waves = {"graph": [], "eager": []}
-    for mode in ("graph", "eager"):
-        for idx in range(2):
-            d = Hn.clip_inputs(S, Fr, seed=1234 + 10 * rank + idx)
-            vid = pipes[mode](d["ref_image"], d["face_emb"], d["audio"], d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr,
-                              steps, 1.0, motion_scale=d["motion_scale"], latents=d["latents"], output_type="device").videos
-            frames = vid[0].permute(1, 0, 2, 3).reshape(Fr, 3, S * S).contiguous()
-            waves[mode].append(cp.gather_wave(ops.frames_to_uint8(frames)))     # [F, HW, 3] uint8: RCCL all-gather right behind the replayed graph
+
+    def one(pipe, idx):
+        d = Hn.clip_inputs(S, Fr, seed=1234 + 10 * rank + idx)
+        vid = pipe(d["ref_image"], d["face_emb"], d["audio"], d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr,
+                   steps, 1.0, motion_scale=d["motion_scale"], latents=d["latents"], output_type="device").videos
+        frames = vid[0].permute(1, 0, 2, 3).reshape(Fr, 3, S * S).contiguous()
+        return cp.gather_wave(ops.frames_to_uint8(frames))       # [world, F, HW, 3] uint8: RCCL all-gather right behind the clip
+    for idx in range(nclips):
+        with torch.cuda.stream(gs[idx % slots]):
+            waves["graph"].append(one(gp[idx % slots], idx))
     torch.cuda.synchronize()
-    (sg,) = pipes["graph"]._graphs.values()
-    assert sg.graph is not None and sg.replays == 2 * (steps - 1)
+    for idx in range(nclips):
+        waves["eager"].append(one(ep, idx))
+    torch.cuda.synchronize()
+    replays = 0
+    for p_ in gp:
+        (sg,) = p_._graphs.values()
+        assert sg.graph is not None
+        replays += sg.replays
+    assert replays == nclips * (steps - 1)
     for a, b in zip(waves["graph"], waves["eager"]):
         assert a.shape[0] == world and torch.equal(a, b)
     assert not torch.equal(waves["graph"][0], waves["graph"][1])
     if rank == 0:
-        torch.save({"replays": sg.replays, "world": world}, os.path.join(out_dir, "ok.pt"))
+        torch.save({"replays": replays, "world": world}, os.path.join(out_dir, "ok.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -139,5 +158,5 @@ def test_graph_replay_next_to_rccl_world1(tmp_path, report):
                 p.kill()
             pytest.fail("graph capture / replay next to RCCL did not finish in 420 s")
     ok = torch.load(tmp_path / "ok.pt")
-    assert ok["replays"] == 6
+    assert ok["replays"] == 12
     report.append({"test": "graph_replay_next_to_rccl_world1", "replays": ok["replays"], "world": 1, "byte_identical_to_eager": True})
