@@ -152,13 +152,17 @@ class OpProfiler:
         def c_rs(a, k, r):
             return 3.0 * a[0].numel(), es * a[0].numel()            # one read pass
 
+        def c_ff(a, k, r):
+            rows = a[0].shape[0]           # LayerNorm -> GEGLU (2 x 1280 x 320) -> net[2] (320 x 1280) -> + residual, one kernel: x read (+ residual), y written
+            return 6.0 * rows * 1280 * 320, es * (3 * rows * 320) + a[1].numel()
+
         def c_fx(a, k, r):
             rows, Cd = a[0].shape          # LN + 32-pair cross-attention + out projection: 2 x (2 * rows * C * 32) flop
             return 4.0 * rows * Cd * 32, es * 2 * rows * Cd
 
         table = dict(gemm=c_gemm, gemm_batched=c_gemmb, conv3x3=c_conv, attention=c_attn, temporal_attention=c_tattn,
                      groupnorm=c_gn, layernorm=c_ln, copy2d=c_copy, softmax_rows=c_sm, nchw_to_nhwc=c_small,
-                     nhwc_to_nchw_f32=c_small, timestep_embedding=c_small, cfg_ddim_step=c_small, face_xattn=c_fx, row_stats=c_rs)
+                     nhwc_to_nchw_f32=c_small, timestep_embedding=c_small, cfg_ddim_step=c_small, face_xattn=c_fx, row_stats=c_rs, ff320=c_ff)
         for name, cost in table.items():
             self._orig[name] = getattr(ops, name)
             setattr(ops, name, self._wrap(name, self._orig[name], cost))
@@ -334,6 +338,7 @@ def main():
                          "the weights, so that one clip's low-occupancy phases (16x16 / 8x8 levels, tails of every launch) are filled by "
                          "another clip's kernels.  Throughput metric: the K timed clips are the same work, issued back to back.  Same box, "
                          "same binary: 16.08 frames/s with 1, 17.7 with 2, 17.9 with 3 or 4, 17.6 with 6 (profiles/r4_inflight_ab.json)")
+    ap.add_argument("--latency-routing", action="store_true", help="A/B: keep the one-clip kernel routing (library defaults) with clips in flight")
     ap.add_argument("--no-slot-wait", action="store_true", help="A/B: do not wait (blocking event) for a slot's previous clip before enqueuing its next one")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: hallo_set_option(NAME, VALUE) before the pipeline is built (e.g. gemm4=0); recorded in config.options")
@@ -409,6 +414,10 @@ def main():
         from hallo_amd import ops as _ops
         if args.gemm_variant is not None:
             _ops.set_option("gemm_variant", args.gemm_variant)
+        # three clips in flight: the kernel routing for throughput (hallo_amd/ops.py THROUGHPUT_OPTIONS: +7 % over the one-clip routing
+        # at --inflight 3, -4 % at --inflight 1); --set-option overrides
+        if args.inflight > 1 and not args.latency_routing:
+            _ops.set_mode(True)
         for kv in args.set_option:
             k_, v_ = kv.split("=")
             _ops.set_option(k_, int(v_))
@@ -559,6 +568,7 @@ def main():
                    "host_cpu_ms_per_clip": round(cpu_s / args.steps * 1e3, 1),
                    "host_cores_per_rank": len(pinned) if pinned else len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                    "options": args.set_option or None,
+                   "kernel_routing": ("throughput: " + str(_ops.THROUGHPUT_OPTIONS) if (not dry and args.inflight > 1 and not args.latency_routing) else "library defaults"),
                    "clips_in_flight_per_gpu": n_slots,
                    "warmup_clips_run": max(args.warmup, n_slots if args.warmup > 0 else 0),
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (

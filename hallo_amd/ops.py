@@ -52,6 +52,25 @@ def option_epoch():
     return _option_epoch
 
 
+# Kernel routing for THROUGHPUT: several independent clips in flight on one GPU (bench.py --inflight).  The
+# library's defaults are tuned for one clip at a time, where the lowest-latency kernel wins; with another clip's kernels ready to
+# fill every idle CU the winners change -- measured on MI355X, alternating runs on one box (profiles/r4_throughput_options_ab.json):
+#   gemm_rs = 0   the row-stationary K = 320 / 640 GEMMs (one 133 KB-LDS workgroup per CU, all CUs in the same phase) -> the tiled
+#                 kernels + hallo_row_stats: two to four co-resident workgroups leave room for the other clips        +3.9 %
+#   ff_fused = 1  the 320-wide feed-forward as one kernel (a third of the HBM bytes; 13 % slower in isolation)          +1.8 %
+#   gn_fused = 0  single-launch GroupNorm of the small maps -> statistics + apply launches                               +3.4 %
+#   gemm4 = 0     the exact-fit one-workgroup-per-CU GEMM -> split big tile                                              +2.5 %
+# together 17.9 -> 19.3 frames/s at three clips in flight (one clip at a time the same set LOSES 4 %: 15.6 against 16.2).
+THROUGHPUT_OPTIONS = {"gemm_rs": 0, "ff_fused": 1, "gn_fused": 0, "gemm4": 0}
+LATENCY_OPTIONS = {"gemm_rs": 2, "ff_fused": 0, "gn_fused": 1, "gemm4": 1}          # the library defaults
+
+
+def set_mode(throughput):
+    """Route the kernels for several clips in flight (True) or for one clip at a time (False, the library defaults)."""
+    for k, v in (THROUGHPUT_OPTIONS if throughput else LATENCY_OPTIONS).items():
+        set_option(k, v)
+
+
 def get_option(name):
     return _l.load().hallo_get_option(name.encode())
 

@@ -25,8 +25,10 @@ def test_full_size_bodies_replay(Fz, dtype):
         Fz.test_full_unet3d_forward(dtype, case, rep)
     Fz.test_full_vae(dtype, rep)
     Fz.test_full_pipeline_config0_geometry(dtype, rep)
+    for name in Fz.TRAJ:                       # the round-4 trajectory tests (eager on the emulation: no graphs on the CPU)
+        Fz.test_full_pipeline_trajectory(dtype, name, "latency", rep)
     Fz.test_zz_release_cache(rep)
-    assert len(rep) == 1 + len(Fz.CASES) + 2 + 2 and all(r["arch"] == "small" for r in rep)
+    assert len(rep) == 1 + len(Fz.CASES) + 2 + 2 + 2 * len(Fz.TRAJ) and all(r["arch"] == "small" for r in rep)
 
 
 def test_round_both_is_exact_in_both_types():

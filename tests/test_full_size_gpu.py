@@ -512,14 +512,18 @@ def _traj_oracle(name):
     return _CACHE[key]
 
 
+@pytest.mark.parametrize("routing", ["throughput", "latency"])
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("name", list(TRAJ))
-def test_full_pipeline_trajectory(dtype, name, report):
+def test_full_pipeline_trajectory(dtype, name, routing, report):
     """FaceAnimatePipeline.__call__ (hallo/animate/face_animate.py:249-442) with use_graph=True -- step 0 eager, step 1
     captured, steps 2.. replayed: the launch path bench.py times -- over the whole trajectory at the benchmarked size, against
     the fp32 oracle: bit-exact schedule indices, rel-L2 of the latents after every kept step (bound 5e-2), PSNR of the
-    decoded frames (>= 35 dB)."""
+    decoded frames (>= 35 dB).  Under both kernel routings: "throughput" = hallo_amd.ops.THROUGHPUT_OPTIONS, what bench.py sets
+    for its clips in flight (tiled K = 320 GEMMs + hallo_row_stats, the fused 320-wide feed-forward kernel, two-launch GroupNorm);
+    "latency" = the library defaults."""
     from oracle import harness as Hn
+    from hallo_amd import ops
     from hallo_amd.animate.face_animate import FaceAnimatePipeline
     from hallo_amd.scheduler import DDIMScheduler
     c = _traj_cfg(name)
@@ -532,23 +536,30 @@ def test_full_pipeline_trajectory(dtype, name, report):
     pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
                                face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched, use_graph=graph)
     seen = []
-    vid_n = pipe(*args, motion_scale=d["motion_scale"], latents=lat,
-                 callback=lambda i, t, l: seen.append((int(t), l.float().cpu() if i + 1 in c["keep"] else None))).videos
-    if graph:
-        (sg,) = pipe._graphs.values()
-        assert sg.graph is not None and sg.replays == c["steps"] - 1
-    pipe.reset_graphs()
+    ops.set_mode(routing == "throughput")
+    try:
+        vid_n = pipe(*args, motion_scale=d["motion_scale"], latents=lat,
+                     callback=lambda i, t, l: seen.append((int(t), l.float().cpu() if i + 1 in c["keep"] else None))).videos
+        if graph:
+            (sg,) = pipe._graphs.values()
+            assert sg.graph is not None and sg.replays == c["steps"] - 1
+            if routing == "throughput" and ARCH == "full":
+                assert ops.get_option("ff_fused") == 1 and ops.get_option("gemm_rs") == 0
+    finally:
+        ops.set_mode(False)
+        pipe.reset_graphs()
     assert [t for t, _ in seen] == [int(t) for t in ref["timesteps"]] and len(seen) == c["steps"]
     kept = [l for _, l in seen if l is not None]
     assert len(kept) == len(ref["latents"]) == len(c["keep"])
     per_step = [Hn.rel_l2(a, b) for a, b in zip(kept, ref["latents"])]
     _rec(report, f"full_{name}_latents[{c['S']}x{c['S']}x{c['Fr']}f,{c['steps']} steps,gs={c['gs']}]", dtype, max(per_step), 5e-2,
-         steps_kept=c["keep"], per_step=[round(v, 6) for v in per_step], oracle=ref["oracle"], launch="hipGraph replay" if graph else "eager")
+         steps_kept=c["keep"], per_step=[round(v, 6) for v in per_step], oracle=ref["oracle"], launch="hipGraph replay" if graph else "eager",
+         kernel_routing=routing)
     assert max(per_step) <= 5e-2, per_step
     assert vid_n.shape == (1, 3, c["Fr"], c["S"], c["S"])
     p = Hn.psnr(vid_n[:, :, c["frames"]], ref["video"])
     report.append({"test": f"full_{name}_frames_psnr[{c['S']}x{c['S']}x{c['Fr']}f,{c['steps']} steps,gs={c['gs']}]", "dtype": str(dtype),
-                   "arch": ARCH, "psnr_db": p, "tol_psnr_db": 35.0, "frames_compared": c["frames"]})
+                   "arch": ARCH, "psnr_db": p, "tol_psnr_db": 35.0, "frames_compared": c["frames"], "kernel_routing": routing})
     print("PSNR", p)
     assert p >= 35.0
 
