@@ -782,6 +782,7 @@ static int g_v3_min_tiles = 192; // auto: smallest grid (workgroups, 1 per CU) w
 // 1000 * LNF (gemm2: 0 none, 1 in-loop LayerNorm statistics, 2 external) + 100 * kernel (1 gemm_kernel, 2 gemm2_kernel,
 // 3 gemm3_kernel) + 10 * mode (0 gemm, 1 conv, 2 geglu) + stages / TM (+ 4 for the persistent gemm3 mode)
 static int g_last_kernel = 0;
+static int g_stage_min_tiles = 640;  // hallo_set_option("gemm_stage_min_tiles", n): grids of >= n tiles take the 1-stage 128x128 kernel (4 workgroups per CU), smaller ones the 2-stage form
 static int g_gemm4_min_nk = 40;  // hallo_set_option("gemm4_min_nk", n): shortest K loop (64-deep steps) the auto rule gives to gemm4.hip (A/B)
 static int g_gemm4 = 1;          // hallo_set_option("gemm4", 0 off | 1 auto rule | 2 every problem gemm4.hip covers): exact-fit / stream-K kernel
 static int g_last_splits = 1;    // hallo_get_option("last_gemm_splits"): split-K factor of the last launch (gemm4: 1000 + parts of a tail tile, 1 = none)
@@ -921,7 +922,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
   const int tiles = a.tiles_m * a.tiles_n;
   // auto: one LDS stage (4 workgroups per CU hide each other's load latency) when the grid fills the chip several
   // times over, two stages (in-workgroup prefetch) for small grids
-  if (v == 3) v = (tiles * batch >= 640) ? 1 : 2;
+  if (v == 3) v = (tiles * batch >= g_stage_min_tiles) ? 1 : 2;
   if (v != 0 && !geglu && !lnf && batch == 1 && g_split_k && ws && tiles < 384 && nk >= 32) {
     // small grids with a long K loop (8x8 / 16x16 feature maps, K up to 23040): split K so that >= ~768 workgroups
     // are in flight; partial sums go to an fp32 slab and a second pass applies the epilogue in a fixed order
@@ -1078,6 +1079,7 @@ extern "C" int hallo_get_option(const char* name) {
   if (!strcmp(name, "last_gemm_splits")) return g_last_splits;
   if (!strcmp(name, "gemm4")) return g_gemm4;
   if (!strcmp(name, "gemm4_min_nk")) return g_gemm4_min_nk;
+  if (!strcmp(name, "gemm_stage_min_tiles")) return g_stage_min_tiles;
   if (!strcmp(name, "gemm_rs")) return g_gemm_rs;
   if (!strcmp(name, "gemm_rs_dbg")) return g_rs_dbg_value;
   if (!strcmp(name, "ff_fused")) return ff_fused_variant();
@@ -1093,6 +1095,7 @@ extern "C" int hallo_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm_rs")) { if (value < 0 || value > 2) return -22; g_gemm_rs = value; return 0; }
   if (!strcmp(name, "gemm4")) { if (value < 0 || value > 2) return -22; g_gemm4 = value; return 0; }
   if (!strcmp(name, "gemm4_min_nk")) { if (value < 4) return -22; g_gemm4_min_nk = value; return 0; }
+  if (!strcmp(name, "gemm_stage_min_tiles")) { if (value < 0) return -22; g_stage_min_tiles = value; return 0; }
   if (!strcmp(name, "ff_fused")) {          // 0 / 1; 2.. = A/B and timing-ablation forms of a -DHALLO_ABLATIONS build
 #ifdef HALLO_ABLATIONS
     if (value < 0 || value > 9) return -22;
