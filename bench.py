@@ -9,9 +9,12 @@ RCCL all-gather of the decoded frames per wave of clips (BASELINE.json configs[3
 A "step" = one clip per rank.  bf16 storage, fp32 accumulation, random-init weights of the reference
 architecture, synthetic inputs.  The K timed clips of a rank are independent (each carries its own reference / motion
 frames, the clip-parallel contract of DESIGN section 8) and are issued back to back over `--inflight` (default 3) pipeline
-objects + HIP streams sharing the weights, so that up to three clips overlap on the GPU (+11 % frames/s over one clip at a
-time: the 16x16 / 8x8 levels and the tail of every launch leave CUs idle that another clip's kernels fill); frames are
-byte-identical to one-at-a-time execution (tests/test_models_gpu.py::test_pipeline_clips_in_flight_are_byte_identical).
+objects + HIP streams sharing the weights, so that up to three clips overlap on the GPU (the 16x16 / 8x8 levels and the tail of
+every launch leave CUs idle that another clip's kernels fill), with the kernel routing for that regime
+(hallo_amd.ops.THROUGHPUT_OPTIONS): 19.33 frames/s against 16.66 one clip at a time on the same box (profiles/
+r4_bench_other_runs.json).  Frames are byte-identical to one-at-a-time execution under the same routing
+(tests/test_models_gpu.py::test_pipeline_clips_in_flight_are_byte_identical); the whole 25-step trajectory is parity-tested under
+both routings (tests/test_full_size_gpu.py::test_full_pipeline_trajectory).
 `ms_per_step` = timed wall time / K (throughput); `clip_latency_ms` = that x clips in flight.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
@@ -337,7 +340,8 @@ def main():
                     help="clips in flight per GPU: consecutive clips alternate over this many (pipeline object, HIP stream) pairs that share "
                          "the weights, so that one clip's low-occupancy phases (16x16 / 8x8 levels, tails of every launch) are filled by "
                          "another clip's kernels.  Throughput metric: the K timed clips are the same work, issued back to back.  Same box, "
-                         "same binary: 16.08 frames/s with 1, 17.7 with 2, 17.9 with 3 or 4, 17.6 with 6 (profiles/r4_inflight_ab.json)")
+                         "same binary, library-default routing: 16.08 frames/s with 1, 17.7 with 2, 17.9 with 3 or 4, 17.6 with 6 "
+                         "(profiles/r4_inflight_ab.json); n > 1 also selects the throughput kernel routing (see --latency-routing)")
     ap.add_argument("--latency-routing", action="store_true", help="A/B: keep the one-clip kernel routing (library defaults) with clips in flight")
     ap.add_argument("--no-slot-wait", action="store_true", help="A/B: do not wait (blocking event) for a slot's previous clip before enqueuing its next one")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",

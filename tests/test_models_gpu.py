@@ -253,7 +253,8 @@ def test_pipeline_hipgraph_survives_reload_and_option_change(nets, report):
     report.append({"test": "pipeline_hipgraph_reload_and_option_change", "dtype": str(dtype), "byte_identical": True})
 
 
-def test_pipeline_clips_in_flight_are_byte_identical(nets, report):
+@pytest.mark.parametrize("routing", ["throughput", "latency"])
+def test_pipeline_clips_in_flight_are_byte_identical(nets, routing, report):
     """bench.py --inflight n (round 4): consecutive independent clips alternate over n (FaceAnimatePipeline, HIP stream) pairs that
     share the networks, so that two or three clips overlap on the GPU.  Shared state must be read-only while clips overlap: every
     clip's frames must equal, byte for byte, the frames of the same clip run alone on one pipeline -- with graph replay (each
@@ -277,6 +278,16 @@ def test_pipeline_clips_in_flight_are_byte_identical(nets, report):
                 [rd(m).to(dev) for m in d["full"]], [rd(m).to(dev) for m in d["face"]], [rd(m).to(dev) for m in d["lip"]], S, S, Fr, steps, 1.0)
         return args, lat.to(dev)
     ins = [inputs(i) for i in range(clips)]
+    from hallo_amd import ops
+    ops.set_mode(routing == "throughput")         # bench.py's kernel routing for clips in flight / the library defaults
+    try:
+        _in_flight_body(ins, mk, kw, slots, clips, dev, FaceAnimatePipeline)
+    finally:
+        ops.set_mode(False)
+    report.append({"test": "pipeline_clips_in_flight_byte_identical", "dtype": str(dtype), "slots": slots, "clips": clips, "kernel_routing": routing})
+
+
+def _in_flight_body(ins, mk, kw, slots, clips, dev, FaceAnimatePipeline):
     alone = FaceAnimatePipeline(scheduler=mk(), **kw)
     ref = [alone(*a, motion_scale=[1.0, 0.8, 1.2], latents=l, output_type="device").videos.clone() for a, l in ins]
     torch.cuda.synchronize()
@@ -297,7 +308,6 @@ def test_pipeline_clips_in_flight_are_byte_identical(nets, report):
         for p_ in pipes:
             p_.reset_graphs()
     assert not torch.equal(ref[0], ref[1])
-    report.append({"test": "pipeline_clips_in_flight_byte_identical", "dtype": str(dtype), "slots": slots, "clips": clips})
 
 
 # ------------------------------------------------------------------------------------------------
