@@ -342,6 +342,7 @@ def main():
                          "another clip's kernels.  Throughput metric: the K timed clips are the same work, issued back to back.  Same box, "
                          "same binary, library-default routing: 16.08 frames/s with 1, 17.7 with 2, 17.9 with 3 or 4, 17.6 with 6 "
                          "(profiles/r4_inflight_ab.json); n > 1 also selects the throughput kernel routing (see --latency-routing)")
+    ap.add_argument("--no-serial-leg", action="store_true", help="skip the one-clip-at-a-time reference leg (rank 0, N = 1; ~5 s)")
     ap.add_argument("--latency-routing", action="store_true", help="A/B: keep the one-clip kernel routing (library defaults) with clips in flight")
     ap.add_argument("--no-slot-wait", action="store_true", help="A/B: do not wait (blocking event) for a slot's previous clip before enqueuing its next one")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
@@ -578,6 +579,34 @@ def main():
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (
                        f" + RCCL all-gather of the decoded frames ({'uint8 video bytes' if gather_u8 else 'fp32'})" if world > 1 else "")},
     }
+
+    # Reference leg (rank 0, N = 1): the same clips ONE AT A TIME with the library-default kernel routing -- the execution of rounds
+    # 1-3 -- so that the line carries both numbers from one process on one box.  3 clips (+ 1 to re-capture the graph of that routing).
+    if not dry and rank == 0 and world == 1 and n_slots > 1 and not args.no_serial_leg:
+        try:
+            _ops.set_mode(False)
+            for kv in args.set_option:
+                k_, v_ = kv.split("=")
+                _ops.set_option(k_, int(v_))
+            sync()
+            run_on(inputs[0], False, pipes[0], hosts[0])                 # captures the graph of this routing (new option epoch)
+            sync()
+            ts = time.perf_counter()
+            nser = min(3, len(inputs))
+            for i in range(nser):
+                run_on(inputs[i], False, pipes[0], hosts[0])
+            sync()
+            tser = time.perf_counter() - ts
+            out["one_clip_at_a_time"] = {"value": nser * Fr / tser, "unit": "frames/s", "clips": nser, "ms_per_clip": tser / nser * 1e3,
+                                         "kernel_routing": "library defaults", "note": "same process, same box, same inputs; rounds 1-3 executed this way"}
+        except Exception as e:
+            out["one_clip_at_a_time"] = {"value": None, "note": f"failed: {type(e).__name__}: {str(e)[:120]}"}
+        finally:
+            if args.inflight > 1 and not args.latency_routing:
+                _ops.set_mode(True)
+            for kv in args.set_option:
+                k_, v_ = kv.split("=")
+                _ops.set_option(k_, int(v_))
 
     if dry:
         out["data"] = "DRY RUN on CPU (control-flow test, the clip is a stub): NOT a measurement"
