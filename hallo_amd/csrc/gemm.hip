@@ -782,6 +782,7 @@ static int g_v3_min_tiles = 192; // auto: smallest grid (workgroups, 1 per CU) w
 // 1000 * LNF (gemm2: 0 none, 1 in-loop LayerNorm statistics, 2 external) + 100 * kernel (1 gemm_kernel, 2 gemm2_kernel,
 // 3 gemm3_kernel) + 10 * mode (0 gemm, 1 conv, 2 geglu) + stages / TM (+ 4 for the persistent gemm3 mode)
 static int g_last_kernel = 0;
+static int g_split_max = 16;         // hallo_set_option("split_k_max", n): cap of the split-K factor (slab traffic grows with it; under concurrency fewer, longer workgroups cost less than they do alone)
 static int g_stage_min_tiles = 640;  // hallo_set_option("gemm_stage_min_tiles", n): grids of >= n tiles take the 1-stage 128x128 kernel (4 workgroups per CU), smaller ones the 2-stage form
 static int g_gemm4_min_nk = 40;  // hallo_set_option("gemm4_min_nk", n): shortest K loop (64-deep steps) the auto rule gives to gemm4.hip (A/B)
 static int g_gemm4 = 1;          // hallo_set_option("gemm4", 0 off | 1 auto rule | 2 every problem gemm4.hip covers): exact-fit / stream-K kernel
@@ -861,6 +862,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
       int f = (256 + tiles - 1) / tiles;
       if (f > nk / 8) f = nk / 8;
       if (f > 8) f = 8;
+      if (f > g_split_max) f = g_split_max;
       while (f > 1 && (int64_t)f * a.M * a.N * 4 > ws_bytes) --f;
       return f < 1 ? 1 : f;
     };
@@ -929,6 +931,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     int sp = (768 + tiles - 1) / tiles;
     if (sp > nk / 4) sp = nk / 4;
     if (sp > 16) sp = 16;
+    if (sp > g_split_max) sp = g_split_max;
     while (sp > 1 && (int64_t)sp * a.M * a.N * 4 > ws_bytes) --sp;
     if (sp > 1) {
       a.nk_per_split = (nk + sp - 1) / sp;
@@ -1080,6 +1083,7 @@ extern "C" int hallo_get_option(const char* name) {
   if (!strcmp(name, "gemm4")) return g_gemm4;
   if (!strcmp(name, "gemm4_min_nk")) return g_gemm4_min_nk;
   if (!strcmp(name, "gemm_stage_min_tiles")) return g_stage_min_tiles;
+  if (!strcmp(name, "split_k_max")) return g_split_max;
   if (!strcmp(name, "gemm_rs")) return g_gemm_rs;
   if (!strcmp(name, "gemm_rs_dbg")) return g_rs_dbg_value;
   if (!strcmp(name, "ff_fused")) return ff_fused_variant();
@@ -1096,6 +1100,7 @@ extern "C" int hallo_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm4")) { if (value < 0 || value > 2) return -22; g_gemm4 = value; return 0; }
   if (!strcmp(name, "gemm4_min_nk")) { if (value < 4) return -22; g_gemm4_min_nk = value; return 0; }
   if (!strcmp(name, "gemm_stage_min_tiles")) { if (value < 0) return -22; g_stage_min_tiles = value; return 0; }
+  if (!strcmp(name, "split_k_max")) { if (value < 1) return -22; g_split_max = value; return 0; }
   if (!strcmp(name, "ff_fused")) {          // 0 / 1; 2.. = A/B and timing-ablation forms of a -DHALLO_ABLATIONS build
 #ifdef HALLO_ABLATIONS
     if (value < 0 || value > 9) return -22;

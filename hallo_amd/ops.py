@@ -61,8 +61,9 @@ def option_epoch():
 #   gn_fused = 0  single-launch GroupNorm of the small maps -> statistics + apply launches                               +3.4 %
 #   gemm4 = 0     the exact-fit one-workgroup-per-CU GEMM -> split big tile                                              +2.5 %
 # together 17.9 -> 19.3 frames/s at three clips in flight (one clip at a time the same set LOSES 4 %: 15.6 against 16.2).
-THROUGHPUT_OPTIONS = {"gemm_rs": 0, "ff_fused": 1, "gn_fused": 0, "gemm4": 0}
-LATENCY_OPTIONS = {"gemm_rs": 2, "ff_fused": 0, "gn_fused": 1, "gemm4": 1}          # the library defaults
+#   split_k_max = 4  split-K factors capped at 4 (8-16 alone): half the slab traffic, fewer but longer workgroups             +0.6 %
+THROUGHPUT_OPTIONS = {"gemm_rs": 0, "ff_fused": 1, "gn_fused": 0, "gemm4": 0, "split_k_max": 4}
+LATENCY_OPTIONS = {"gemm_rs": 2, "ff_fused": 0, "gn_fused": 1, "gemm4": 1, "split_k_max": 16}          # the library defaults
 
 
 def set_mode(throughput):

@@ -39,7 +39,9 @@ int hallo_abi_version(void);
  * 1 / 2 direct-to-LDS 128x128 kernel with 1 / 2 LDS stages, 3 auto among those, 4 / 5 force the 256x320 / 128x320
  * big-tile kernel wherever applicable, 6 auto over all (default), 7 / 8 force the persistent big-tile mode for GEMM / GEGLU;
  * "split_k" = 0 / 1 (auto, default); "gn_fused" = 0 / 1 (single-launch GroupNorm for small feature maps, default 1);
- * "v3_min_tiles" = smallest grid the auto rule gives to the big-tile kernel.  Returns -22 for unknown names / values. */
+ * "v3_min_tiles" = smallest grid the auto rule gives to the big-tile kernel; round 4: "gemm4" = 0 off / 1 auto rule / 2 every
+ * problem csrc/gemm4.hip covers, "gemm4_min_nk", "gemm_stage_min_tiles", "split_k_max" (cap of the split-K factor).
+ * Returns -22 for unknown names / values. */
 int hallo_set_option(const char* name, int value);
 /* Read an option back; "last_gemm_kernel" = the kernel the last hallo_gemm / hallo_conv3x3_nhwc call launched, as
  * 1000 * f + 100 * k + 10 * mode + s: k = 1 gemm_kernel / 2 gemm2_kernel / 3 gemm3_kernel, mode = 0 gemm / 1 conv3x3 /
