@@ -1022,6 +1022,22 @@ extern "C" int hallo_gemm(const hallo_gemm_desc* d, void* stream) {
   return -22;
 }
 
+extern "C" int hallo_gemm4_schedule(int M, int N, int K, int64_t workspace_bytes, int force_parts, int* sched) {
+  // The schedule csrc/gemm4.hip would run a plain M x N x K problem with (pure function of its arguments and of the device's CU
+  // count; 256 without a device): sched[0..7] = tiles_m, tiles_n, K steps, workgroups, data-parallel rounds, tail tiles, parts per
+  // tail tile, K steps per part.  Returns 1 if the kernel covers the problem, 0 if not, -22 on bad arguments.
+  if (M <= 0 || N <= 0 || K <= 0 || !sched) return -22;
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.M = M; a.N = N; a.K = K; a.bias2_rpg = 1; a.res_vec_ok = 1;
+  G4Sched gs;
+  if (!gemm4_plan(a, workspace_bytes, &gs)) return 0;
+  (void)force_parts;
+  sched[0] = gs.tiles_m; sched[1] = gs.tiles_n; sched[2] = gs.nk; sched[3] = gs.G; sched[4] = gs.dp; sched[5] = gs.R;
+  sched[6] = gs.parts; sched[7] = gs.per;
+  return 1;
+}
+
 extern "C" int hallo_gemm_fuses_row_stats(int M, int N, int K, int geglu, int bias2_rows_per_group, int lead_cols) {
   if (!g_gemm_rs || g_gemm_variant < 3) return 0;
   GemmArgs a;

@@ -124,6 +124,7 @@ SYMBOLS = {
                                          C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "hallo_row_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "hallo_gemm_fuses_row_stats": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "hallo_gemm4_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
     "hallo_face_xattn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "hallo_ff320_pack_bytes": (C.c_int64, []),

@@ -253,6 +253,16 @@ int hallo_row_stats(const void* x, float* stats, int64_t rows, int C, float eps,
  * the in-K-loop statistics of the tiled kernel).  Pure function of its arguments and of hallo_set_option("gemm_rs"). */
 int hallo_gemm_fuses_row_stats(int M, int N, int K, int geglu, int bias2_rows_per_group, int lead_cols);
 
+/* hallo_gemm4_schedule (ABI v6, round 4): the work deal csrc/gemm4.hip (exact-fit kernel: 128 x 160 tiles, one persistent workgroup per
+ * CU) would use for a plain M x N x K hallo_gemm problem -- sched[0..7] = tiles_m, tiles_n, K steps of 64, workgroups G,
+ * data-parallel rounds dp (workgroup w owns tiles j * G + w, j < dp, XCD-remapped), tail tiles R = tiles - dp * G, parts per tail
+ * tile (1: whole tiles; > 1: each tail tile's K loop dealt over that many workgroups, partial tiles reduced in K order by the
+ * last arriver), K steps per part.  Pure function of its arguments and of the device's CU count (256 without a device), so the
+ * deal can be checked on a host without a GPU (tests/test_host_cpu.py).  Returns 1 / 0 (the kernel does not cover the problem:
+ * K % 64, too little workspace for a split tail) / -22; `force_parts` is reserved (pass 0).  Which problems hallo_gemm actually
+ * gives to the kernel is the routing rule behind hallo_set_option("gemm4", ...). */
+int hallo_gemm4_schedule(int M, int N, int K, int64_t workspace_bytes, int force_parts, int* sched);
+
 /* ------------------------------------------------------------------------------------------
  * ABI v4: fp8 (OCP e4m3) projections -- BASELINE.json configs[4] "fp8 MFMA QKV/out projections with bf16 accumulate":
  * the diffusers Attention.to_q / to_k / to_v / to_out Linears (hallo/models/mutual_self_attention.py:253-303,

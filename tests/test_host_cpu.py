@@ -129,3 +129,53 @@ def test_clip_cache_refreshes_constants_in_place():
         c.get(owner, "kv", lambda: (torch.zeros(2, 4), torch.zeros(2, 3)))
     c.clear()
     assert c.get(owner, "kv", make(5))[0] is not k0
+
+
+def test_gemm4_schedule_covers_every_tile_and_k_step_once():
+    """The work deal of csrc/gemm4.hip (hallo_gemm4_schedule, computed on the host: no GPU needed), replayed with the kernel's own
+    segment rules for every workgroup: each (tile, K step) of the problem must be owned exactly once, the parts of a split tail
+    tile must be contiguous in K and in workgroup index, and the XCD remap must be a bijection."""
+    import ctypes as C
+    from hallo_amd import build, lib as hl
+    build.build()
+    lib = hl.load()
+
+    def xcd_remap(bid, nwg):
+        q, r = nwg >> 3, nwg & 7
+        xcd, idx = bid & 7, bid >> 3
+        return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + idx
+
+    ws = 128 << 20
+    shapes = [(4096, 1280, 1280), (4096, 1280, 5120), (4096, 3840, 1280), (4608, 3840, 1280), (4608, 1280, 1280), (16384, 640, 640),
+              (18432, 1920, 640), (1024, 1280, 5120), (1152, 3840, 1280), (1000, 1288, 1280), (5000, 648, 704), (128, 160, 256),
+              (65536, 320, 1280), (130, 170, 4096), (256 * 128, 160, 640), (257 * 128, 160, 8192)]
+    seen_split = False
+    for (M, N, K) in shapes:
+        sched = (C.c_int * 8)()
+        ok = lib.hallo_gemm4_schedule(M, N, K, ws, 0, sched)
+        assert ok == 1, (M, N, K, ok)
+        tm, tn, nk, G, dp, R, parts, per = list(sched)
+        assert tm == -(-M // 128) and tn == -(-N // 160) and nk == K // 64 and dp * G + R == tm * tn and 0 <= R < max(G, R + 1)
+        assert sorted(xcd_remap(b, G) for b in range(G)) == list(range(G))
+        if dp:
+            assert sorted(xcd_remap(b, dp * G) for b in range(dp * G)) == list(range(dp * G))
+        owned = {}
+        for bid in range(G):
+            wl = xcd_remap(bid, G)
+            for j in range(dp):
+                t = xcd_remap(j * G + bid, dp * G)
+                for k in range(nk):
+                    owned[(t, k)] = owned.get((t, k), 0) + 1
+            if wl < R * parts:
+                t, q = dp * G + wl // parts, wl % parts
+                kb, ke = q * per, min(nk, q * per + per)
+                assert kb < ke, (M, N, K, wl)                  # every part owns at least one K step
+                for k in range(kb, ke):
+                    owned[(t, k)] = owned.get((t, k), 0) + 1
+        assert len(owned) == tm * tn * nk and set(owned.values()) == {1}, (M, N, K)
+        if parts > 1:
+            seen_split = True
+            assert R * parts <= G and (parts - 1) * per < nk <= parts * per
+    assert seen_split
+    assert lib.hallo_gemm4_schedule(4096, 1280, 1000, ws, 0, (C.c_int * 8)()) == 0      # K % 64 != 0: not covered
+    assert lib.hallo_gemm4_schedule(0, 1280, 1280, ws, 0, (C.c_int * 8)()) == -22
