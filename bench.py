@@ -216,16 +216,57 @@ class OpProfiler:
 UNET_TFLOP = {(128, 4): 0.351, (256, 8): 2.74, (512, 16): 25.59}
 
 
-def usable_cores():
-    """Threads this process may actually run on: affinity mask, capped by the cgroup CPU quota."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+def cpu_quota_cores():
+    """The cgroup CPU quota in cores (cpu.max), or None when there is none."""
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
         if q != "max":
-            n = min(n, max(1, int(float(q) / float(per))))
+            return max(1, int(float(q) / float(per)))
     except Exception:
         pass
+    return None
+
+
+def usable_cores():
+    """Threads this process may actually run on: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    q = cpu_quota_cores()
+    if q is not None:
+        n = min(n, q)
     return max(1, min(n, 64))     # more threads than that only adds fork/join overhead to the oracle's small ops
+
+
+def thread_cpu_times():
+    """{(tid, name): CPU seconds (user + system)} of every thread of this process, from /proc: which of the HIP runtime's helper
+    threads the host time of a clip goes to (1.86 cores busy per rank)."""
+    out = {}
+    try:
+        tck = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                st = open(f"/proc/self/task/{tid}/stat").read()
+                name = st[st.index("(") + 1:st.rindex(")")]
+                f = st[st.rindex(")") + 2:].split()
+                out[(int(tid), name)] = (int(f[11]) + int(f[12])) / tck
+            except Exception:
+                pass
+    except Exception:
+        pass
+    return out
+
+
+def rank_cores(cores, quota, local_rank, world):
+    """The host cores rank `local_rank` of `world` pins itself to: its own 1/world-th of the affinity mask, and of that only as
+    many cores as its share of the cgroup CPU quota (the mask of the GPU pool's boxes shows 256 cores under a 16-core quota: a
+    rank that spreads its launch thread + the HIP runtime's helper threads over 32 cores still only gets 2 cores' worth of
+    time, and migrates for nothing).  Returns a list, or None when there is nothing to pin to."""
+    per = len(cores) // world
+    if per < 1:
+        return None
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    if quota is not None:
+        mine = mine[:max(1, min(per, quota // world))]
+    return mine
 
 
 def cpu_baseline_worker(frames, steps_ddim, budget_s):
@@ -388,10 +429,8 @@ def main():
     # N launch threads (and RCCL's proxy / watchdog threads) do not migrate over each other (N = 1: untouched)
     pinned = None
     if world > 1 and hasattr(os, "sched_setaffinity") and not args.no_pin:
-        cores = sorted(os.sched_getaffinity(0))
-        per = len(cores) // world
-        if per >= 1:
-            pinned = cores[local_rank * per:(local_rank + 1) * per]
+        pinned = rank_cores(sorted(os.sched_getaffinity(0)), cpu_quota_cores(), local_rank, world)
+        if pinned:
             os.sched_setaffinity(0, pinned)
     dry = args.dry_run_cpu
     dist = None
@@ -420,14 +459,16 @@ def main():
         if args.gemm_variant is not None:
             _ops.set_option("gemm_variant", args.gemm_variant)
         # three clips in flight: the kernel routing for throughput (hallo_amd/ops.py THROUGHPUT_OPTIONS: +7 % over the one-clip routing
-        # at --inflight 3, -4 % at --inflight 1); --set-option overrides
-        if args.inflight > 1 and not args.latency_routing:
-            _ops.set_mode(True)
+        # at --inflight 3, -4 % at --inflight 1) -- a property of the pipeline objects (FaceAnimatePipeline(routing=...)), applied
+        # around their enqueue calls, not process state; --set-option overrides
+        routing = dict(_ops.THROUGHPUT_OPTIONS if (args.inflight > 1 and not args.latency_routing) else _ops.LATENCY_OPTIONS)
+        serial_routing = dict(_ops.LATENCY_OPTIONS)
         for kv in args.set_option:
             k_, v_ = kv.split("=")
-            _ops.set_option(k_, int(v_))
+            routing[k_] = serial_routing[k_] = int(v_)
         from hallo_amd.synthetic import build_pipeline, clip_inputs
         pipe, audioproj = build_pipeline(dev, dtype)
+        pipe.routing = routing
         if args.fp8_proj:
             pipe.denoising_unet.set_fp8_projections(True)
         # one hipGraph of the UNet evaluation, captured during the warm-up clip, replayed for steps 1.. of every clip -- at every
@@ -441,8 +482,12 @@ def main():
         from hallo_amd.animate.face_animate import FaceAnimatePipeline as _FAP
         from hallo_amd.synthetic import make_scheduler as _mk
         pipes = [pipe] + [_FAP(vae=pipe.vae, reference_unet=pipe.reference_unet, denoising_unet=pipe.denoising_unet,
-                               face_locator=pipe.face_locator, image_proj=pipe.image_proj, scheduler=_mk(), use_graph=pipe.use_graph)
+                               face_locator=pipe.face_locator, image_proj=pipe.image_proj, scheduler=_mk(), use_graph=pipe.use_graph,
+                               routing=routing)
                           for _ in range(max(1, args.inflight) - 1)]
+        serial_pipe = _FAP(vae=pipe.vae, reference_unet=pipe.reference_unet, denoising_unet=pipe.denoising_unet,
+                           face_locator=pipe.face_locator, image_proj=pipe.image_proj, scheduler=_mk(), use_graph=pipe.use_graph,
+                           routing=serial_routing)
         streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(len(pipes) - 1)]
     from hallo_amd.animate.clip_parallel import gather_wave
     gather_u8 = world > 1 and (args.gather or ("f32" if dry else "u8")) == "u8"
@@ -468,19 +513,23 @@ def main():
     # given back); the clips of the other slots keep the GPU busy meanwhile.
     slot_done = [None] * (1 if dry else len(pipes))
 
-    def run(d, exchange=True, slot=0):
+    # one int64 per timed clip: the sum of the bit patterns of its fp32 frames, written by a reduction on the clip's own stream
+    # (50 MB read, ~15 us of an 800 ms clip) and compared AFTER the timed region with the same clips run alone
+    chk = None if dry else torch.zeros((max(args.steps, 1),), device=dev, dtype=torch.int64)
+
+    def run(d, exchange=True, slot=0, chk_out=None):
         if not dry and len(pipes) > 1:
             if slot_done[slot] is not None and not args.no_slot_wait:
                 slot_done[slot].synchronize()
             with torch.cuda.stream(streams[slot]):
-                r_ = run_on(d, exchange, pipes[slot], hosts[slot])
+                r_ = run_on(d, exchange, pipes[slot], hosts[slot], chk_out)
                 if slot_done[slot] is None:
                     slot_done[slot] = torch.cuda.Event(blocking=True)
                 slot_done[slot].record(streams[slot])
                 return r_
-        return run_on(d, exchange, None if dry else pipes[slot], hosts[slot])
+        return run_on(d, exchange, None if dry else pipes[slot], hosts[slot], chk_out)
 
-    def run_on(d, exchange, pipe, host):
+    def run_on(d, exchange, pipe, host, chk_out=None):
         if dry:
             frames = torch.full((Fr, 3, S * S), d["stub"])
         else:
@@ -490,6 +539,8 @@ def main():
             h = S // 8
             lat = lat[0].permute(1, 2, 3, 0).reshape(Fr * h * h, 4).contiguous()
             frames, _, _ = pipe.decode_latents_device(lat, Fr, h, h)
+            if chk_out is not None:
+                torch.sum(frames.view(torch.int32), dtype=torch.int64, out=chk_out)
         if world > 1 and exchange:
             if gather_u8:      # the video bytes, converted on the device: 4x fewer bytes over xGMI and PCIe
                 send = (frames.clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 1).contiguous() if dry else _ops.frames_to_uint8(frames)
@@ -538,13 +589,24 @@ def main():
     t0 = time.perf_counter()
     host_s = 0.0
     cpu0 = time.process_time()
+    thr0 = time.thread_time()
+    tcpu0 = thread_cpu_times()
     for i in range(args.steps):
         th = time.perf_counter()
-        run(inputs[args.warmup + i], slot=i % n_slots)
+        run(inputs[args.warmup + i], slot=i % n_slots, chk_out=None if dry else chk[i])
         host_s += time.perf_counter() - th      # wall time inside the enqueue calls of a clip: includes the runtime's back-pressure
+    cpu_main_s = time.thread_time() - thr0      # CPU time of the launch thread alone
     cpu_s = time.process_time() - cpu0          # when the hardware queue is full (25 replays x ~690 packets); CPU time of the process
     fence()
     elapsed = time.perf_counter() - t0
+    tcpu1 = thread_cpu_times()
+    by_thread = {}
+    for k_, v_ in tcpu1.items():
+        dv = v_ - tcpu0.get(k_, 0.0)
+        if dv > 0:
+            nm = ("launch thread: " if k_[0] == os.getpid() else "") + k_[1]
+            by_thread[nm] = by_thread.get(nm, 0.0) + dv
+    by_thread = {k_: round(v_ / args.steps * 1e3, 1) for k_, v_ in sorted(by_thread.items(), key=lambda kv: -kv[1])[:6]}
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -571,42 +633,57 @@ def main():
                    "launch": ("hipGraph replay of the UNet evaluation (steps 1.. of every clip)" if (not dry and pipe.use_graph) else (graph_note or "eager")),
                    "host_wall_in_enqueue_calls_ms_per_clip": round(host_s / args.steps * 1e3, 1),
                    "host_cpu_ms_per_clip": round(cpu_s / args.steps * 1e3, 1),
+                   "host_cpu_launch_thread_ms_per_clip": round(cpu_main_s / args.steps * 1e3, 1),
+                   "host_cores_busy_per_rank": round(cpu_s / elapsed, 2),
+                   "host_cpu_ms_per_clip_by_thread": by_thread,
                    "host_cores_per_rank": len(pinned) if pinned else len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                   "host_cpu_quota_cores": cpu_quota_cores(),
                    "options": args.set_option or None,
-                   "kernel_routing": ("throughput: " + str(_ops.THROUGHPUT_OPTIONS) if (not dry and args.inflight > 1 and not args.latency_routing) else "library defaults"),
+                   "kernel_routing": ("dry run" if dry else ("throughput: " if (args.inflight > 1 and not args.latency_routing) else "library defaults: ") + str(routing)),
                    "clips_in_flight_per_gpu": n_slots,
                    "warmup_clips_run": max(args.warmup, n_slots if args.warmup > 0 else 0),
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (
                        f" + RCCL all-gather of the decoded frames ({'uint8 video bytes' if gather_u8 else 'fp32'})" if world > 1 else "")},
     }
 
+    # Identity leg (every rank): the first timed clips again, ALONE (device idle before and after each), same pipeline objects, same
+    # routing, same graphs -- their frame checksums must equal the ones the timed clips left behind while three clips overlapped.
+    # A race between clips in flight (shared scratch, a constant rebuilt under another clip) fails here, and the line says so.
+    if not dry and n_slots > 1:
+        nchk = min(n_slots, args.steps)
+        alone = torch.zeros((nchk,), device=dev, dtype=torch.int64)
+        for i in range(nchk):
+            sync()
+            run(inputs[args.warmup + i], exchange=False, slot=0, chk_out=alone[i])
+        sync()
+        same = bool(torch.equal(alone, chk[:nchk]))
+        if world > 1:
+            flag = torch.tensor([0 if same else 1], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            same = int(flag.item()) == 0
+        out["inflight_identity"] = {"clips_checked_per_rank": nchk, "identical": same,
+                                    "how": "int64 sum of the fp32 frames' bit patterns: timed clip i (three in flight) == the same clip run alone afterwards on slot 0"}
+        if not same:
+            out["INVALID"] = "frames of clips in flight differ from the same clips run alone: the headline is void"
+
     # Reference leg (rank 0, N = 1): the same clips ONE AT A TIME with the library-default kernel routing -- the execution of rounds
-    # 1-3 -- so that the line carries both numbers from one process on one box.  3 clips (+ 1 to re-capture the graph of that routing).
+    # 1-3 -- so that the line carries both numbers from one process on one box.  3 clips (+ 1 to capture the graph of that routing).
     if not dry and rank == 0 and world == 1 and n_slots > 1 and not args.no_serial_leg:
         try:
-            _ops.set_mode(False)
-            for kv in args.set_option:
-                k_, v_ = kv.split("=")
-                _ops.set_option(k_, int(v_))
             sync()
-            run_on(inputs[0], False, pipes[0], hosts[0])                 # captures the graph of this routing (new option epoch)
+            run_on(inputs[0], False, serial_pipe, hosts[0])              # captures the graph of this routing
             sync()
             ts = time.perf_counter()
             nser = min(3, len(inputs))
             for i in range(nser):
-                run_on(inputs[i], False, pipes[0], hosts[0])
+                run_on(inputs[i], False, serial_pipe, hosts[0])
             sync()
             tser = time.perf_counter() - ts
             out["one_clip_at_a_time"] = {"value": nser * Fr / tser, "unit": "frames/s", "clips": nser, "ms_per_clip": tser / nser * 1e3,
                                          "kernel_routing": "library defaults", "note": "same process, same box, same inputs; rounds 1-3 executed this way"}
         except Exception as e:
             out["one_clip_at_a_time"] = {"value": None, "note": f"failed: {type(e).__name__}: {str(e)[:120]}"}
-        finally:
-            if args.inflight > 1 and not args.latency_routing:
-                _ops.set_mode(True)
-            for kv in args.set_option:
-                k_, v_ = kv.split("=")
-                _ops.set_option(k_, int(v_))
+        serial_pipe.reset_graphs()
 
     if dry:
         out["data"] = "DRY RUN on CPU (control-flow test, the clip is a stub): NOT a measurement"

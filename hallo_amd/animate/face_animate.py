@@ -61,13 +61,27 @@ class StepGraph:
 class FaceAnimatePipeline:
     MAX_GRAPHS = 2          # captured (geometry, batch, ...) keys kept alive at a time
 
-    def __init__(self, vae, reference_unet, denoising_unet, face_locator, image_proj, scheduler, use_graph=False):
+    def __init__(self, vae, reference_unet, denoising_unet, face_locator, image_proj, scheduler, use_graph=False, routing=None):
+        """routing: the kernel routing this pipeline's launches are enqueued (and its graphs captured) under -- "latency" (the
+        library defaults: one clip at a time), "throughput" (several pipelines in flight on one GPU: ops.THROUGHPUT_OPTIONS), a
+        dict of hallo_set_option values, or None = whatever the process has set.  Applied around the enqueue calls of a clip
+        (ops.routing) and restored afterwards: a process may run pipelines of both kinds side by side."""
         self.vae, self.reference_unet, self.denoising_unet = vae, reference_unet, denoising_unet
         self.face_locator, self.image_proj, self.scheduler = face_locator, image_proj, scheduler
         self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
         self.timings = {}
         self.use_graph = use_graph
+        self.routing = routing
         self._graphs = {}
+        self._scratch = None
+
+    @property
+    def scratch(self):
+        """Launch scratch (split-K slab, GroupNorm partial statistics) of THIS pipeline: its eager launches and its captured
+        graphs use nothing else, so pipelines in flight on different streams never share a producer -> consumer buffer."""
+        if self._scratch is None:
+            self._scratch = ops.Scratch(self.device)
+        return self._scratch
 
     def reset_graphs(self):
         """Drop every captured UNet graph (after changing a kernel option with ops.set_option, or to release their memory)."""
@@ -106,10 +120,14 @@ class FaceAnimatePipeline:
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def __call__(self, ref_image, face_emb, audio_tensor, face_mask, pixel_values_full_mask, pixel_values_face_mask,
-                 pixel_values_lip_mask, width, height, video_length, num_inference_steps, guidance_scale,
-                 num_images_per_prompt=1, eta=0.0, motion_scale=None, generator=None, output_type="tensor",
-                 return_dict=True, callback=None, callback_steps=1, latents=None, decode=True, **kwargs):
+    def __call__(self, *args, **kwargs):
+        with ops.routing(self.routing), ops.scratch_scope(self.scratch):
+            return self._call(*args, **kwargs)
+
+    def _call(self, ref_image, face_emb, audio_tensor, face_mask, pixel_values_full_mask, pixel_values_face_mask,
+              pixel_values_lip_mask, width, height, video_length, num_inference_steps, guidance_scale,
+              num_images_per_prompt=1, eta=0.0, motion_scale=None, generator=None, output_type="tensor",
+              return_dict=True, callback=None, callback_steps=1, latents=None, decode=True, **kwargs):
         if eta != 0.0:
             raise ValueError("the Hallo path runs DDIM with eta = 0 (face_animate.py:420)")
         dev = self.device
@@ -149,7 +167,7 @@ class FaceAnimatePipeline:
             refnet.prepare()
             ms_key = None if motion_scale is None else tuple(float(m) for m in motion_scale)
             key = (B, Fr, h, w, dt, str(dev), ref_image.shape[1] if ref_image.dim() == 5 else ref_image.shape[0], ms_key,
-                   tuple(audio_tensor.shape[-2:]), tuple(enc.shape[1:]), ops.option_epoch(),
+                   tuple(audio_tensor.shape[-2:]), tuple(enc.shape[1:]), ops.options_fingerprint(),
                    bool(getattr(den, "fp8_projections", False)), den.prepare_epoch)
             sg = self._graphs.get(key)
             if sg is None:
@@ -230,6 +248,10 @@ class FaceAnimatePipeline:
     # ------------------------------------------------------------------------------------------
     def decode_latents_device(self, lat, frames, h, w):
         """fp32 token-major latents [F*L, C] -> fp32 device tensor [F, 3, H*W] in [0, 1]."""
+        with ops.routing(self.routing), ops.scratch_scope(self.scratch):
+            return self._decode_latents_device(lat, frames, h, w)
+
+    def _decode_latents_device(self, lat, frames, h, w):
         dt = self.denoising_unet.dtype
         C_lat = lat.shape[-1]
         z = torch.zeros((frames, h * w, 8), device=lat.device, dtype=dt)

@@ -1016,13 +1016,15 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
   return -22;
 }
 
+extern "C" int hallo_get_option_norm(const char* name);
+
 extern "C" int hallo_get_option_attn(const char* name) {
   if (name && !strcmp(name, "attn40")) return g_attn40;
   if (name && !strcmp(name, "temporal_mfma")) return g_temporal_mfma;
   if (name && !strcmp(name, "attn_order")) return g_attn_order;
   if (name && !strcmp(name, "tok_attn")) return g_tok_attn;
   if (name && !strcmp(name, "last_attn_kernel")) return g_last_attn;
-  return -22;
+  return hallo_get_option_norm(name);      // norm_elementwise.hip: gn_fused (-> fused_xattn.hip: xattn_tiled)
 }
 
 extern "C" int hallo_set_option_xattn(const char* name, int value);

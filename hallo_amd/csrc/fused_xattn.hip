@@ -301,6 +301,11 @@ extern "C" int hallo_set_option_xattn(const char* name, int value) {
   return -2;
 }
 
+extern "C" int hallo_get_option_xattn(const char* name) {
+  if (name && !strcmp(name, "xattn_tiled")) return g_xattn_tiled;
+  return -22;
+}
+
 extern "C" int hallo_face_xattn(const void* x, void* y, const void* sg, const float* g, const float* b, const void* owp,
                                 const void* bo, int64_t rows, int C, int64_t rows_per_batch, float eps, int dtype,
                                 void* stream) {

@@ -1103,6 +1103,7 @@ extern "C" int hallo_get_option(const char* name) {
   if (!strcmp(name, "gemm_rs")) return g_gemm_rs;
   if (!strcmp(name, "gemm_rs_dbg")) return g_rs_dbg_value;
   if (!strcmp(name, "ff_fused")) return ff_fused_variant();
+  if (!strcmp(name, "conv_fast")) return g_conv_fast;
   return hallo_get_option_attn(name);
 }
 

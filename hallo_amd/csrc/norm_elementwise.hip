@@ -655,6 +655,13 @@ extern "C" int hallo_set_option_norm(const char* name, int value) {
   return hallo_set_option_attn(name, value);
 }
 
+extern "C" int hallo_get_option_xattn(const char* name);            // fused_xattn.hip
+
+extern "C" int hallo_get_option_norm(const char* name) {
+  if (name && !strcmp(name, "gn_fused")) return g_gn_fused;
+  return hallo_get_option_xattn(name);
+}
+
 extern "C" int hallo_groupnorm_chunks(int HW) {
   int c = (HW + 63) / 64;   // 64 rows per partial-statistics block: >= 1024 blocks at 16 x 64x64 frames
   if (c > 64) c = 64;

@@ -325,6 +325,7 @@ class FeedForward(nn.Module):
         if self._ff_pack_ok and ops.ff320_enabled(N * L):
             if self._ff_pack is None:
                 self._ff_pack = ops.ff320_pack(self._ln_w, self._ln_b, self.net[2].weight)
+                ops.publish_constant()          # shared by every pipeline / stream that runs this module
             return ops.ff320(x2, self._ff_pack, self.net[2].bias, eps=self._ln_eps).view(N, L, Cd)
         h = ops.gemm(x2, self._ln_w, self._ln_b, geglu=True, ln_colsum=self._ln_g, ln_eps=self._ln_eps,
                      ln_stats=ops.ln_stats(x2, self._ln_w.shape[0] // 2, self._ln_eps, geglu=True))

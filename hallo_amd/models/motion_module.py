@@ -66,6 +66,7 @@ class TemporalTransformerBlock(nn.Module):
             pe = attn.pos_encoder.pe32[:frames].to(attn.w_qkv.dtype)                       # the buffer follows the model dtype
             rows = ops.gemm(pe.contiguous(), attn.w_qkv)                                   # [frames, 3C]
             self._pe_bias[key] = rows.repeat(batch, 1).contiguous()
+            ops.publish_constant()              # shared by every pipeline / stream that runs this module
         return self._pe_bias[key]
 
     def run(self, h, batch, frames, drop=0):

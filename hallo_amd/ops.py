@@ -41,15 +41,32 @@ _option_epoch = 0
 
 
 def set_option(name, value):
-    """Kernel A/B switch, e.g. set_option('gemm_variant', 0|1|2).  Bumps `option_epoch()`: captured hipGraphs hold the
-    kernels the options routed to at capture time, so FaceAnimatePipeline keys its graphs on the epoch."""
+    """Kernel A/B switch, e.g. set_option('gemm_variant', 0|1|2).  Bumps `option_epoch()` when the value CHANGES: captured
+    hipGraphs hold the kernels the options routed to at capture time, so FaceAnimatePipeline keys its graphs on the epoch.
+    Returns the previous value (None for write-only options)."""
     global _option_epoch
-    _l.check(_l.load().hallo_set_option(name.encode(), int(value)), f"hallo_set_option({name})")
+    lib = _l.load()
+    prev = lib.hallo_get_option(name.encode())
+    if prev == int(value):
+        return prev
+    _l.check(lib.hallo_set_option(name.encode(), int(value)), f"hallo_set_option({name})")
     _option_epoch += 1
+    return prev if prev >= 0 else None
 
 
 def option_epoch():
     return _option_epoch
+
+
+ROUTING_OPTION_NAMES = ("gemm_variant", "split_k", "split_k_max", "v3_min_tiles", "gemm4", "gemm4_min_nk", "gemm_stage_min_tiles",
+                        "gemm_rs", "ff_fused", "conv_fast", "attn40", "temporal_mfma", "attn_order", "tok_attn", "gn_fused", "xattn_tiled")
+
+
+def options_fingerprint():
+    """Values of every option that decides which kernel a launch is routed to: what a captured graph is valid for (the epoch
+    counts CHANGES, and a routing scope that sets and restores options changes it twice per clip without changing anything)."""
+    lib = _l.load()
+    return tuple(lib.hallo_get_option(n.encode()) for n in ROUTING_OPTION_NAMES)
 
 
 # Kernel routing for THROUGHPUT: several independent clips in flight on one GPU (bench.py --inflight, DESIGN section 7.1).  The
@@ -64,34 +81,121 @@ def option_epoch():
 #   split_k_max = 4  split-K factors capped at 4 (8-16 alone): half the slab traffic, fewer but longer workgroups             +0.6 %
 THROUGHPUT_OPTIONS = {"gemm_rs": 0, "ff_fused": 1, "gn_fused": 0, "gemm4": 0, "split_k_max": 4}
 LATENCY_OPTIONS = {"gemm_rs": 2, "ff_fused": 0, "gn_fused": 1, "gemm4": 1, "split_k_max": 16}          # the library defaults
+ROUTINGS = {"throughput": THROUGHPUT_OPTIONS, "latency": LATENCY_OPTIONS}
+
+
+class routing:
+    """`with ops.routing("throughput" | "latency" | {option: value} | None):` -- kernel routing as a property of the CALLER
+    (FaceAnimatePipeline(routing=...)) instead of process-global state: the options are read by the library at ENQUEUE time (and
+    baked into a graph at capture time), so a scope around the enqueue calls is all a pipeline needs; the previous values come
+    back on exit, and an option that already has the wanted value is not touched (no epoch bump, captured graphs stay valid).
+    None = leave everything as it is.  Host-side only: two host threads enqueueing under different routings must serialise."""
+
+    def __init__(self, options):
+        self.options = ROUTINGS[options] if isinstance(options, str) else options
+        self._prev = None
+
+    def __enter__(self):
+        if self.options:
+            self._prev = {k: set_option(k, v) for k, v in self.options.items()}
+        return self
+
+    def __exit__(self, *exc):
+        if self._prev:
+            for k, v in self._prev.items():
+                if v is not None:
+                    set_option(k, v)
+        self._prev = None
+        return False
 
 
 def set_mode(throughput):
-    """Route the kernels for several clips in flight (True) or for one clip at a time (False, the library defaults)."""
-    for k, v in (THROUGHPUT_OPTIONS if throughput else LATENCY_OPTIONS).items():
-        set_option(k, v)
+    """Process-wide default routing (kept for tools / old command lines; pipelines carry their own `routing`): several clips in
+    flight (True) or one clip at a time (False, the library defaults).  Returns the previous values: `restore_options(prev)`."""
+    return {k: set_option(k, v) for k, v in (THROUGHPUT_OPTIONS if throughput else LATENCY_OPTIONS).items()}
+
+
+def restore_options(prev):
+    for k, v in (prev or {}).items():
+        if v is not None:
+            set_option(k, v)
 
 
 def get_option(name):
     return _l.load().hallo_get_option(name.encode())
 
 
-_splitk_ws = {}
 SPLITK_WS_BYTES = 128 << 20
+GN_WS_FLOATS = 1 << 20
+
+
+class Scratch:
+    """The launch scratch of ONE in-order sequence of launches (a pipeline object, a captured graph): the fp32 split-K /
+    stream-K slab of hallo_gemm / hallo_conv3x3_nhwc and the partial-statistics buffer of hallo_groupnorm_nhwc.  Both are
+    written by one launch and read by the next one on the same stream, so two sequences that may overlap on the GPU must never
+    share them.  Fixed addresses (a captured launch stays replayable).  The slab's last 64 KB hold the arrival counters of
+    csrc/gemm4.hip's K-split tail: zero before the first launch, restored to zero by every launch."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.splitk = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
+        self.splitk[-(65536 // 4):].zero_()
+        self.gn = torch.empty(GN_WS_FLOATS, device=device, dtype=torch.float32)
+
+    def gn_ws(self, need):
+        if self.gn.numel() < need:
+            if torch.cuda.is_current_stream_capturing():
+                raise _l.HalloLibraryError(f"GroupNorm scratch of {need} floats needed inside a graph capture, {self.gn.numel()} allocated")
+            self.gn = torch.empty(need, device=self.device, dtype=torch.float32)
+        return self.gn
+
+
+_scratch_stack = []
+_stream_scratch = {}
+
+
+class scratch_scope:
+    """`with ops.scratch_scope(s):` every launch enqueued inside uses the Scratch `s` (FaceAnimatePipeline wraps its clip in one:
+    eager step 0 and the captured graph of a pipeline share that pipeline's scratch, other pipelines have their own).  Outside any
+    scope the scratch is keyed by (device, current stream) -- NOTE that inside `torch.cuda.graph(...)` the current stream is
+    torch's capture stream, one per process unless the caller passes `stream=`: graphs captured without a scope on that default
+    stream would all bake in the same buffers and must not be replayed concurrently (round-4 ADVICE)."""
+
+    def __init__(self, scratch):
+        self.scratch = scratch
+
+    def __enter__(self):
+        _scratch_stack.append(self.scratch)
+        return self.scratch
+
+    def __exit__(self, *exc):
+        _scratch_stack.pop()
+        return False
+
+
+def current_scratch(device):
+    if _scratch_stack and _scratch_stack[-1] is not None:
+        return _scratch_stack[-1]
+    device = torch.device(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    s = _stream_scratch.get(key)
+    if s is None:
+        s = _stream_scratch[key] = Scratch(device)
+    return s
 
 
 def _workspace(device):
-    """fp32 scratch for split-K / stream-K partial sums: one fixed buffer per (device, stream) -- a fixed address keeps captured
-    launches replayable, and two streams never share partial sums.  ZERO-initialised: the last 64 KB hold the arrival counters
-    of csrc/gemm4.hip's K-split tail, which must be zero before the first launch and are restored to zero by every launch (the
-    slab / partial-tile area below them needs no initialisation)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _splitk_ws.get(key)
-    if ws is None:
-        ws = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
-        ws[-(65536 // 4):].zero_()          # the counters only: a workspace first seen inside a graph capture re-zeroes 64 KB per replay, not 128 MB
-        _splitk_ws[key] = ws
-    return ws
+    return current_scratch(device).splitk
+
+
+def publish_constant():
+    """Call after building a lazily created constant that lives on a shared module (weight images, positional-encoding bias
+    rows): other pipelines read it from THEIR streams without any ordering against the stream that built it, so the build is
+    made visible with a one-off host wait on the current stream.  Lazy constants are built during a clip's eager step 0; inside a
+    graph capture a host wait is impossible and the constant would live in the graph's private pool -- refuse."""
+    if torch.cuda.is_current_stream_capturing():
+        raise _l.HalloLibraryError("a shared constant was first built inside a graph capture: run one eager evaluation first")
+    torch.cuda.current_stream().synchronize()
 
 
 def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, act=ACT_NONE, geglu=False,
@@ -278,9 +382,6 @@ def temporal_attention(qkv, B, F, HW, Cdim, heads, *, out=None, scale=None):
     return out
 
 
-_gn_ws = {}
-
-
 def groupnorm(x, gamma, beta, n_img, HW, groups, eps, *, silu=False, out=None):
     """Per-frame GroupNorm (+SiLU) on x [n_img, HW, C]."""
     _chk_dev(x)
@@ -289,12 +390,7 @@ def groupnorm(x, gamma, beta, n_img, HW, groups, eps, *, silu=False, out=None):
     if out is None:
         out = torch.empty_like(x)
     lib = _l.load()
-    need = n_img * lib.hallo_groupnorm_chunks(HW) * groups * 2
-    key = (x.device, torch.cuda.current_stream().cuda_stream)
-    ws = _gn_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 1 << 16), device=x.device, dtype=torch.float32)
-        _gn_ws[key] = ws
+    ws = current_scratch(x.device).gn_ws(n_img * lib.hallo_groupnorm_chunks(HW) * groups * 2)
     _l.check(lib.hallo_groupnorm_nhwc(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), n_img, HW, Cdim, groups, float(eps),
                                       1 if silu else 0, dtype_code(x.dtype), _stream()), "hallo_groupnorm_nhwc")
     return out

@@ -40,6 +40,22 @@ def get_option(name):
     return 0
 
 
+def options_fingerprint():
+    return ()
+
+
+def publish_constant():
+    return None
+
+
+class Scratch:
+    """The emulation has no launch scratch (no split-K slabs, no partial statistics)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.splitk = self.gn = None
+
+
 def _act_post(v, act):
     if act == ACT_SILU:
         return F.silu(v)
@@ -347,7 +363,7 @@ def lerp_rows(x, out_rows):
     return F.interpolate(x.float().t()[None], size=out_rows, mode="linear", align_corners=True)[0].t().contiguous().to(x.dtype)
 
 
-EMULATED = ("dtype_code", "set_option", "get_option", "gemm", "gemm_batched", "conv3x3", "attention", "temporal_attention",
+EMULATED = ("dtype_code", "set_option", "get_option", "options_fingerprint", "publish_constant", "Scratch", "gemm", "gemm_batched", "conv3x3", "attention", "temporal_attention",
             "groupnorm", "layernorm", "row_stats", "ln_stats", "ff320_enabled", "softmax_rows", "copy2d", "nchw_to_nhwc", "nhwc_to_nchw_f32",
             "timestep_embedding", "cfg_ddim_step", "frames_to_uint8", "face_xattn", "w2v_conv0_gn_gelu", "lerp_rows")
 

@@ -27,6 +27,8 @@ def test_full_size_bodies_replay(Fz, dtype):
     Fz.test_full_pipeline_config0_geometry(dtype, rep)
     for name in Fz.TRAJ:                       # the round-4 trajectory tests (eager on the emulation: no graphs on the CPU)
         Fz.test_full_pipeline_trajectory(dtype, name, "latency", rep)
+    if dtype == torch.bfloat16:                # round 5: the in-flight identity test's "alone" half (inputs, routing attribute, scratch scope)
+        Fz.test_clips_in_flight_identity_at_the_benchmarked_configuration(rep)
     Fz.test_zz_release_cache(rep)
     assert len(rep) == 1 + len(Fz.CASES) + 2 + 2 + 2 * len(Fz.TRAJ) and all(r["arch"] == "small" for r in rep)
 

@@ -179,3 +179,46 @@ def test_gemm4_schedule_covers_every_tile_and_k_step_once():
     assert seen_split
     assert lib.hallo_gemm4_schedule(4096, 1280, 1000, ws, 0, (C.c_int * 8)()) == 0      # K % 64 != 0: not covered
     assert lib.hallo_gemm4_schedule(0, 1280, 1280, ws, 0, (C.c_int * 8)()) == -22
+
+
+def test_routing_is_a_scope_not_process_state():
+    """Round 5: the kernel routing belongs to a pipeline and is applied around its enqueue calls.  `ops.routing`
+    sets only the options that differ, restores the previous values on exit (whatever they were -- not hard-coded defaults),
+    and does not bump the option epoch when nothing changes; `options_fingerprint` is what captured graphs are keyed on."""
+    from hallo_amd import ops
+    base = ops.options_fingerprint()
+    user_prev = ops.set_option("split_k_max", 8)                  # a user-set value that set_mode(False) used to clobber
+    try:
+        before = ops.options_fingerprint()
+        e0 = ops.option_epoch()
+        with ops.routing("throughput"):
+            inside = ops.options_fingerprint()
+            assert ops.get_option("gemm_rs") == 0 and ops.get_option("gn_fused") == 0 and ops.get_option("split_k_max") == 4
+            e1 = ops.option_epoch()
+            with ops.routing(dict(ops.THROUGHPUT_OPTIONS)):     # nested, same values: nothing is touched
+                assert ops.option_epoch() == e1
+            assert ops.options_fingerprint() == inside
+        assert ops.options_fingerprint() == before and ops.get_option("split_k_max") == 8
+        assert ops.option_epoch() > e0
+        with ops.routing(None):
+            assert ops.options_fingerprint() == before
+        e2 = ops.option_epoch()
+        assert ops.set_option("split_k_max", 8) == 8 and ops.option_epoch() == e2          # unchanged value: no epoch bump
+    finally:
+        ops.set_option("split_k_max", user_prev)
+    assert ops.options_fingerprint() == base
+    assert inside != before and len(base) == len(ops.ROUTING_OPTION_NAMES) and all(v >= 0 for v in base)
+
+
+def test_rank_core_slices_respect_the_cgroup_quota():
+    """bench.py pins each rank to min(affinity share, quota share) cores (the pool's boxes show 256 cores in the mask
+    under a 16-core cgroup quota)."""
+    import bench
+    cores = list(range(256))
+    sl = [bench.rank_cores(cores, 16, r, 8) for r in range(8)]
+    assert all(len(s) == 2 for s in sl) and sl[0] == [0, 1] and sl[7] == [224, 225]
+    assert len({c for s in sl for c in s}) == 16
+    assert bench.rank_cores(cores, None, 3, 8) == list(range(96, 128))             # no quota: the whole share of the mask
+    assert bench.rank_cores(cores, 4, 1, 8) == [32]                                # quota below one core per rank: one core each
+    assert bench.rank_cores(list(range(4)), 16, 0, 8) is None                      # fewer cores than ranks: no pinning
+    assert bench.rank_cores(list(range(16)), 64, 1, 2) == list(range(8, 16))

@@ -279,11 +279,10 @@ def test_pipeline_clips_in_flight_are_byte_identical(nets, routing, report):
         return args, lat.to(dev)
     ins = [inputs(i) for i in range(clips)]
     from hallo_amd import ops
-    ops.set_mode(routing == "throughput")         # bench.py's kernel routing for clips in flight / the library defaults
-    try:
-        _in_flight_body(ins, mk, kw, slots, clips, dev, FaceAnimatePipeline)
-    finally:
-        ops.set_mode(False)
+    kw["routing"] = routing                       # bench.py's kernel routing for clips in flight / the library defaults
+    before = ops.options_fingerprint()
+    _in_flight_body(ins, mk, kw, slots, clips, dev, FaceAnimatePipeline)
+    assert ops.options_fingerprint() == before
     report.append({"test": "pipeline_clips_in_flight_byte_identical", "dtype": str(dtype), "slots": slots, "clips": clips, "kernel_routing": routing})
 
 
