@@ -540,7 +540,7 @@ def main():
             lat = lat[0].permute(1, 2, 3, 0).reshape(Fr * h * h, 4).contiguous()
             frames, _, _ = pipe.decode_latents_device(lat, Fr, h, h)
             if chk_out is not None:
-                torch.sum(frames.view(torch.int32), dtype=torch.int64, out=chk_out)
+                torch.sum(frames.view(torch.int32).view(-1), dim=(0,), keepdim=True, dtype=torch.int64, out=chk_out)
         if world > 1 and exchange:
             if gather_u8:      # the video bytes, converted on the device: 4x fewer bytes over xGMI and PCIe
                 send = (frames.clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 1).contiguous() if dry else _ops.frames_to_uint8(frames)
@@ -593,7 +593,7 @@ def main():
     tcpu0 = thread_cpu_times()
     for i in range(args.steps):
         th = time.perf_counter()
-        run(inputs[args.warmup + i], slot=i % n_slots, chk_out=None if dry else chk[i])
+        run(inputs[args.warmup + i], slot=i % n_slots, chk_out=None if dry else chk[i:i + 1])
         host_s += time.perf_counter() - th      # wall time inside the enqueue calls of a clip: includes the runtime's back-pressure
     cpu_main_s = time.thread_time() - thr0      # CPU time of the launch thread alone
     cpu_s = time.process_time() - cpu0          # when the hardware queue is full (25 replays x ~690 packets); CPU time of the process
@@ -654,7 +654,7 @@ def main():
         alone = torch.zeros((nchk,), device=dev, dtype=torch.int64)
         for i in range(nchk):
             sync()
-            run(inputs[args.warmup + i], exchange=False, slot=0, chk_out=alone[i])
+            run(inputs[args.warmup + i], exchange=False, slot=0, chk_out=alone[i:i + 1])
         sync()
         same = bool(torch.equal(alone, chk[:nchk]))
         if world > 1:

@@ -4,9 +4,9 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
 O=gpurun_out
 cat /sys/fs/cgroup/cpu.max > $O/r5_box.txt 2>&1; nproc >> $O/r5_box.txt; python -c "import os;print(len(os.sched_getaffinity(0)))" >> $O/r5_box.txt
-timeout 900 python -m pytest tests/test_full_size_gpu.py -x -q -k "in_flight_identity" > $O/r5_identity.log 2>&1
-echo "identity rc=$?" >> $O/r5_identity.log
-tail -3 $O/r5_identity.log
+timeout 900 python -m pytest tests/test_models_gpu.py -x -q -k "in_flight or hipgraph" > $O/r5_models_inflight.log 2>&1
+echo "models rc=$?" >> $O/r5_models_inflight.log
+tail -3 $O/r5_models_inflight.log
 timeout 600 python bench.py > $O/r5_bench_default.json 2> $O/r5_bench_default.err
 echo "bench rc=$?"; cut -c1-600 $O/r5_bench_default.json
 B="--no-cpu-baseline --no-profile --no-serial-leg --steps 9 --warmup 3"
