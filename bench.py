@@ -361,6 +361,53 @@ def cpu_baseline(frames, steps_ddim, budget_s=150.0):
     return best
 
 
+def configs2_leg(pipe, audioproj, dev, S, Fr, n_clips, make_scheduler, dtype):
+    """BASELINE.json configs[2] = the reference's DEFAULT run (configs/inference/default.yaml:4-18: 40 DDIM steps, CFG 3.5) on the
+    path the reference actually executes: ONE video, its clips in sequence (scripts/inference.py:285-347; clip t+1 needs the last
+    two decoded frames of clip t), through hallo_amd.animate.video.generate_video.  Two executions from one process:
+      sequential   one B = 2 evaluation per step, the whole clip decoded before the next one starts (rounds 1-4);
+      overlapped   FaceAnimatePipeline(cfg_split=True) -- the cond / uncond halves of every evaluation as two B = 1 graphs on two
+                   streams -- and generate_video(overlap_decode=True) -- the last two frames decoded first, the other 14 decoded /
+                   converted / copied underneath the next clip.
+    Each is warmed by a one-clip video (graph capture), then timed on an n_clips-clip video ending in a device synchronise."""
+    from hallo_amd.animate import video as V
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline as FAP
+    g = torch.Generator().manual_seed(99)
+    lat = S // 8
+    src = (torch.rand((3, S, S), generator=g) * 2 - 1).to(dev)
+    region = torch.zeros((3, S, S))
+    region[:, S // 4: 3 * S // 4, S // 4: 3 * S // 4] = 1.0
+    region = region.to(dev)
+    emb = torch.randn((512,), generator=g).to(dev)
+    mk = lambda: [torch.rand((1, (lat // 2 ** l) ** 2), generator=g) for l in range(4)]
+    fm, cm, lm = mk(), mk(), mk()
+    audio = torch.randn((n_clips * Fr, 12, 768), generator=g).to(dev, dtype)
+    kw = dict(clip_length=Fr, n_motion_frames=2, img_size=(S, S), inference_steps=40, cfg_scale=3.5, motion_scale=[1.0, 1.0, 1.0],
+              output="uint8")
+    nets = dict(vae=pipe.vae, reference_unet=pipe.reference_unet, denoising_unet=pipe.denoising_unet, face_locator=pipe.face_locator,
+                image_proj=pipe.image_proj)
+    res = {}
+    for name, pkw, vkw in (("sequential", dict(routing="latency"), {}),
+                           ("overlapped", dict(routing="latency", cfg_split=True), dict(overlap_decode=True)),
+                           ("overlapped_throughput_routing", dict(routing="throughput", cfg_split=True), dict(overlap_decode=True))):
+        p_ = FAP(scheduler=make_scheduler(), use_graph=True, **nets, **pkw)
+        V.generate_video(p_, audioproj, src, region, emb, fm, cm, lm, audio[:Fr], **kw, **vkw)           # warm-up: captures the graph(s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        u8 = V.generate_video(p_, audioproj, src, region, emb, fm, cm, lm, audio, **kw, **vkw)
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        res[name] = {"frames_per_s": round(n_clips * Fr / dt_, 3), "ms_per_clip": round(dt_ / n_clips * 1e3, 1), "frames": int(u8.shape[0])}
+        p_.reset_graphs()
+        del p_
+        torch.cuda.empty_cache()
+    best = max(("overlapped", "overlapped_throughput_routing"), key=lambda k: res[k]["frames_per_s"])
+    return {"workload": f"BASELINE.json configs[2]: one video of {n_clips} sequential clips, {S}x{S}, {Fr} frames, 40 DDIM steps, CFG 3.5 "
+                        "(B = 2), generate_video -> uint8 frames on the host",
+            "value": res[best]["frames_per_s"], "unit": "frames/s", "execution": best,
+            "vs_sequential": round(res[best]["frames_per_s"] / res["sequential"]["frames_per_s"], 3), **res}
+
+
 # ------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -383,6 +430,8 @@ def main():
                          "another clip's kernels.  Throughput metric: the K timed clips are the same work, issued back to back.  Same box, "
                          "same binary, library-default routing: 16.08 frames/s with 1, 17.7 with 2, 17.9 with 3 or 4, 17.6 with 6 "
                          "(profiles/r4_inflight_ab.json); n > 1 also selects the throughput kernel routing (see --latency-routing)")
+    ap.add_argument("--no-configs2", action="store_true", help="skip the configs[2] leg (the reference's default run on the sequential video path; ~40 s)")
+    ap.add_argument("--configs2-clips", type=int, default=3)
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the one-clip-at-a-time reference leg (rank 0, N = 1; ~5 s)")
     ap.add_argument("--latency-routing", action="store_true", help="A/B: keep the one-clip kernel routing (library defaults) with clips in flight")
     ap.add_argument("--no-slot-wait", action="store_true", help="A/B: do not wait (blocking event) for a slot's previous clip before enqueuing its next one")
@@ -684,6 +733,14 @@ def main():
         except Exception as e:
             out["one_clip_at_a_time"] = {"value": None, "note": f"failed: {type(e).__name__}: {str(e)[:120]}"}
         serial_pipe.reset_graphs()
+
+    # the reference's default configuration on the sequential video path (rank 0, N = 1)
+    if not dry and rank == 0 and world == 1 and not args.no_configs2 and (S, Fr) == (512, 16):
+        try:
+            sync()
+            out["configs2"] = configs2_leg(pipe, audioproj, dev, S, Fr, args.configs2_clips, _mk, dtype)
+        except Exception as e:
+            out["configs2"] = {"value": None, "note": f"failed: {type(e).__name__}: {str(e)[:200]}"}
 
     if dry:
         out["data"] = "DRY RUN on CPU (control-flow test, the clip is a stub): NOT a measurement"

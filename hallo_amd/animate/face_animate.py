@@ -26,7 +26,7 @@ from dataclasses import dataclass
 import torch
 
 from .. import ops
-from ..models.attention import ClipCache
+from ..models.attention import SKIP_BANK, ClipCache
 from ..models.mutual_self_attention import ReferenceAttentionControl
 from ..models.unet_3d import pack_masks
 from .image_processor import preprocess_image
@@ -42,13 +42,17 @@ class StepGraph:
     evaluation go through ctypes at 3-4 us of host time each; behind the sub-10-us kernels of the 8x8 / 16x16 levels the GPU
     waits for the host (3 % of a clip in launch gaps, profiles/r2_bench_launch_gaps.json).  A replay is one host call."""
 
-    def __init__(self, B, Fr, L, C0, device, dtype):
+    def __init__(self, B, Fr, L, C0, device, dtype, split=False, out_channels=4):
         self.x_in = torch.zeros((B * Fr, L, 8), device=device, dtype=dtype)
         self.mask_cond = torch.zeros((B * Fr, L, C0), device=device, dtype=dtype)
         self.t_dev = torch.zeros((B,), device=device, dtype=torch.float32)
         self.cache = ClipCache()
         self.graph, self.out = None, None
         self.replays = 0
+        # cfg_split: the uncond / cond halves of a CFG evaluation as two B = 1 evaluations (own clip cache, own graph, own
+        # timestep tensor each) that read their halves of x_in / mask_cond and write their halves of ONE output buffer
+        self.halves = [StepGraph(1, 0, L, 8, device, dtype) for _ in range(2)] if split else None
+        self.v_out = torch.empty((B * Fr, L, out_channels), device=device, dtype=dtype) if split else None
 
     def capture(self, fn):
         g = torch.cuda.CUDAGraph()
@@ -61,8 +65,14 @@ class StepGraph:
 class FaceAnimatePipeline:
     MAX_GRAPHS = 2          # captured (geometry, batch, ...) keys kept alive at a time
 
-    def __init__(self, vae, reference_unet, denoising_unet, face_locator, image_proj, scheduler, use_graph=False, routing=None):
-        """routing: the kernel routing this pipeline's launches are enqueued (and its graphs captured) under -- "latency" (the
+    def __init__(self, vae, reference_unet, denoising_unet, face_locator, image_proj, scheduler, use_graph=False, routing=None,
+                 cfg_split=False):
+        """cfg_split: under classifier-free guidance run the uncond and the cond half of every UNet evaluation as two B = 1
+        evaluations on two HIP streams, joined at the fused CFG + DDIM kernel (they share nothing but read-only weights and
+        banks, hallo/animate/face_animate.py:397-417; the uncond half has no bank segment at all).  The clips of ONE video are
+        sequential (scripts/inference.py:302-310), so this is how a second evaluation gets in flight inside one clip: the CUs
+        one half leaves idle (16 x 16 / 8 x 8 levels, launch tails, dependent-launch bubbles) take the other half's kernels.
+        routing: the kernel routing this pipeline's launches are enqueued (and its graphs captured) under -- "latency" (the
         library defaults: one clip at a time), "throughput" (several pipelines in flight on one GPU: ops.THROUGHPUT_OPTIONS), a
         dict of hallo_set_option values, or None = whatever the process has set.  Applied around the enqueue calls of a clip
         (ops.routing) and restored afterwards: a process may run pipelines of both kinds side by side."""
@@ -72,8 +82,10 @@ class FaceAnimatePipeline:
         self.timings = {}
         self.use_graph = use_graph
         self.routing = routing
+        self.cfg_split = cfg_split
         self._graphs = {}
-        self._scratch = None
+        self._scratch = self._scratch_aux = self._aux_stream = None
+        self._scratch_decode = self._decode_stream = None
 
     @property
     def scratch(self):
@@ -82,6 +94,28 @@ class FaceAnimatePipeline:
         if self._scratch is None:
             self._scratch = ops.Scratch(self.device)
         return self._scratch
+
+    @property
+    def scratch_aux(self):
+        """Launch scratch of this pipeline's SECOND stream (the uncond half under cfg_split, the trailing VAE decode of
+        animate.video.generate_video(overlap_decode=True))."""
+        if self._scratch_aux is None:
+            self._scratch_aux = ops.Scratch(self.device)
+        return self._scratch_aux
+
+    @property
+    def aux_stream(self):
+        if self._aux_stream is None:
+            self._aux_stream = torch.cuda.Stream(self.device)
+        return self._aux_stream
+
+    @property
+    def decode_side(self):
+        """(stream, launch scratch) of the trailing VAE decode of animate.video.generate_video(overlap_decode=True)."""
+        if self._decode_stream is None:
+            self._decode_stream = torch.cuda.Stream(self.device)
+            self._scratch_decode = ops.Scratch(self.device)
+        return self._decode_stream, self._scratch_decode
 
     def reset_graphs(self):
         """Drop every captured UNet graph (after changing a kernel option with ops.set_option, or to release their memory)."""
@@ -158,6 +192,7 @@ class FaceAnimatePipeline:
         lat5 = self.prepare_latents(1, C_lat, width, height, Fr, dt, dev, generator, latents)
         lat = lat5[0].permute(1, 2, 3, 0).reshape(Fr * L, C_lat).float().contiguous()
         C0 = den.config.block_out_channels[0]
+        split = bool(do_cfg and self.cfg_split)
         sg = None
         if self.use_graph:
             # prepare() is lazy: after den.load_state_dict() / den.to() the weight images (and prepare_epoch) of the NEXT forward
@@ -168,7 +203,7 @@ class FaceAnimatePipeline:
             ms_key = None if motion_scale is None else tuple(float(m) for m in motion_scale)
             key = (B, Fr, h, w, dt, str(dev), ref_image.shape[1] if ref_image.dim() == 5 else ref_image.shape[0], ms_key,
                    tuple(audio_tensor.shape[-2:]), tuple(enc.shape[1:]), ops.options_fingerprint(),
-                   bool(getattr(den, "fp8_projections", False)), den.prepare_epoch)
+                   bool(getattr(den, "fp8_projections", False)), bool(do_cfg and self.cfg_split), den.prepare_epoch)
             sg = self._graphs.get(key)
             if sg is None:
                 # graphs of re-prepared weights (another prepare_epoch) point at freed weight images, and every graph pins the
@@ -177,7 +212,7 @@ class FaceAnimatePipeline:
                     del self._graphs[k]
                 while len(self._graphs) >= self.MAX_GRAPHS:
                     del self._graphs[next(iter(self._graphs))]
-                sg = self._graphs[key] = StepGraph(B, Fr, L, C0, dev, dt)
+                sg = self._graphs[key] = StepGraph(B, Fr, L, C0, dev, dt, split=split, out_channels=den.conv_out.cout)
         x_in = sg.x_in if sg is not None else torch.zeros((B * Fr, L, 8), device=dev, dtype=dt)
         x_in.view(B, Fr * L, 8)[:, :, :C_lat] = lat.to(dt)
 
@@ -203,7 +238,13 @@ class FaceAnimatePipeline:
             audio = torch.cat([torch.zeros_like(audio), audio], dim=0)
         audio = audio.reshape(B * Fr, audio.shape[-2], audio.shape[-1]).contiguous()
 
-        if sg is not None:
+        if split:
+            halves = sg.halves if sg is not None else [StepGraph(1, 0, L, 8, dev, dt) for _ in range(2)]
+            v_out = sg.v_out if sg is not None else torch.empty((B * Fr, L, den.conv_out.cout), device=dev, dtype=dt)
+            for hf in halves:
+                hf.cache.begin_clip()
+            cache = None
+        elif sg is not None:
             cache = sg.cache
             cache.begin_clip()          # step 0 (eager) refreshes the per-clip constants inside their old storage
         else:
@@ -213,7 +254,12 @@ class FaceAnimatePipeline:
                 # ReferenceNet write pass on [ref, m1, m2] (x2 under CFG) at t = 0 (face_animate.py:386-395)
                 refnet.written_banks = refnet.forward_tokens(ref_lat.repeat(B, 1, 1), 0, enc, h, w)
                 reader.update(writer)
-            if sg is not None and i > 0:
+            if split:
+                v = self._split_eval(halves, sg is not None and i > 0, t, x_in, v_out, enc, den.reference_bank, audio, mask_cond,
+                                     masks, motion_scale, Fr, h, w)
+                if sg is not None and i > 0:
+                    sg.replays += 1
+            elif sg is not None and i > 0:
                 sg.t_dev.fill_(float(t))
                 if sg.graph is None:
                     sg.capture(lambda: den.forward_tokens(x_in, sg.t_dev, enc, den.reference_bank, audio, mask_cond, masks,
@@ -230,7 +276,7 @@ class FaceAnimatePipeline:
                 callback(i, t, lat.view(Fr, h, w, C_lat).permute(3, 0, 1, 2).unsqueeze(0).to(dt))
         reader.clear()
         writer.clear()
-        if sg is None:
+        if sg is None and cache is not None:
             cache.clear()
         if not decode:
             return lat.view(Fr, h, w, C_lat).permute(3, 0, 1, 2).unsqueeze(0)
@@ -245,10 +291,42 @@ class FaceAnimatePipeline:
             return video
         return FaceAnimatePipelineOutput(videos=video)
 
+    def _split_eval(self, halves, graphed, t, x_in, v_out, enc, banks, audio, mask_cond, masks, motion_scale, Fr, h, w):
+        """One CFG evaluation as two B = 1 evaluations: uncond (rows 0..Fr of every [2 Fr, ...] tensor, bank rows 0..2, no bank
+        segment in the spatial self-attention) on the auxiliary stream with its own launch scratch, cond (rows Fr.., motion-frame
+        features = bank rows 4..5, reference features ALTERNATING between bank rows 0 and 3 over the frames: the reference tiles
+        the bank over the batch axis, mutual_self_attention.py:235-247) on the current stream; both write their half of `v_out`; the current stream then waits for the auxiliary one, so the
+        caller's fused CFG + DDIM kernel sees both halves.  graphed: replay (capture on first use) each half's hipGraph."""
+        den = self.denoising_unet
+        on_gpu = self.device.type == "cuda"
+        if on_gpu:
+            main, aux = torch.cuda.current_stream(), self.aux_stream
+            aux.wait_stream(main)           # x_in (the previous DDIM update) and this clip's banks / constants are ready
+        import contextlib
+        for hi, flag in enumerate((SKIP_BANK, False)):
+            hf, rows = halves[hi], slice(hi * Fr, (hi + 1) * Fr)
+            with (torch.cuda.stream(aux if hi == 0 else main) if on_gpu else contextlib.nullcontext()), \
+                    ops.scratch_scope(self.scratch_aux if hi == 0 else self.scratch):
+                args = (enc[hi:hi + 1], banks, audio[rows], mask_cond[rows],
+                        [tuple(m[rows] for m in md) for md in masks], motion_scale, 1, Fr, h, w, flag, hf.cache)
+                kw = dict(out=v_out[rows], bank_layout=(2, hi, hi * Fr))
+                if graphed:
+                    hf.t_dev.fill_(float(t))
+                    if hf.graph is None:
+                        hf.capture(lambda: den.forward_tokens(x_in[rows], hf.t_dev, *args, **kw))
+                    hf.graph.replay()
+                    hf.replays += 1
+                else:
+                    den.forward_tokens(x_in[rows], int(t), *args, **kw)
+        if on_gpu:
+            main.wait_stream(aux)
+        return v_out
+
     # ------------------------------------------------------------------------------------------
-    def decode_latents_device(self, lat, frames, h, w):
-        """fp32 token-major latents [F*L, C] -> fp32 device tensor [F, 3, H*W] in [0, 1]."""
-        with ops.routing(self.routing), ops.scratch_scope(self.scratch):
+    def decode_latents_device(self, lat, frames, h, w, scratch=None):
+        """fp32 token-major latents [F*L, C] -> fp32 device tensor [F, 3, H*W] in [0, 1].  scratch: the launch scratch of the
+        stream this decode is enqueued on when that is not the pipeline's own (decode_side)."""
+        with ops.routing(self.routing), ops.scratch_scope(scratch if scratch is not None else self.scratch):
             return self._decode_latents_device(lat, frames, h, w)
 
     def _decode_latents_device(self, lat, frames, h, w):

@@ -35,13 +35,19 @@ def frames_to_uint8(video):
 def generate_video(pipeline, audioproj, source_image_pixels, source_image_face_region, source_image_face_emb,
                    full_mask, face_mask, lip_mask, audio_emb, *, clip_length=16, n_motion_frames=2, img_size=(512, 512),
                    inference_steps=40, cfg_scale=3.5, motion_scale=None, audio_length=None, seed=42,
-                   output="float", on_clip=None):
+                   output="float", on_clip=None, overlap_decode=False):
     """The clip loop of scripts/inference.py:265-343.
 
     source_image_pixels (3, H, W) in [-1, 1]; source_image_face_region (3, H, W); source_image_face_emb (512,);
     full/face/lip_mask: lists of 4 tensors (1, (H/8/2^l)^2); audio_emb (T, 12, 768) raw wav2vec hidden-state stack.
     Returns (3, audio_length, H, W) fp32 on the CPU (output="float", the reference's tensor) or uint8
-    (audio_length, H, W, 3) (output="uint8", what tensor_to_video feeds the encoder)."""
+    (audio_length, H, W, 3) (output="uint8", what tensor_to_video feeds the encoder).
+
+    overlap_decode (GPU only; SURVEY section 8 f1, second half): clip t+1 needs only the LAST n_motion_frames decoded frames of
+    clip t (scripts/inference.py:302-306), so those are decoded first on the pipeline's stream, clip t+1 starts right behind
+    them, and the other clip_length - n_motion_frames frames of clip t are decoded, converted and copied out on a second
+    stream underneath it.  Same sequential semantics; the frames of a clip come from two VAE batches instead of one (the VAE
+    is per-frame arithmetic: hallo/animate/face_animate.py:237-245 decodes frame by frame)."""
     dev = source_image_pixels.device
     audio_emb = process_audio_emb(audio_emb)
     src = source_image_pixels.unsqueeze(0)
@@ -64,11 +70,18 @@ def generate_video(pipeline, audioproj, source_image_pixels, source_image_face_r
             motion = prev[0].permute(1, 0, 2, 3)[-n_motion_frames:] * 2.0 - 1.0   # last frames of clip t-1, back to [-1, 1]
         ref_img = torch.cat([src, motion.to(src.dtype)], dim=0).unsqueeze(0)
         audio_tensor = audioproj(audio_emb[t * clip_length:(t + 1) * clip_length].unsqueeze(0))
-        out = pipeline(ref_image=ref_img, audio_tensor=audio_tensor, face_emb=face_emb, face_mask=face_region,
-                       pixel_values_full_mask=full_mask, pixel_values_face_mask=face_mask,
-                       pixel_values_lip_mask=lip_mask, width=img_size[0], height=img_size[1], video_length=clip_length,
-                       num_inference_steps=inference_steps, guidance_scale=cfg_scale, generator=generator,
-                       motion_scale=motion_scale, **({"output_type": "device"} if on_gpu else {}))
+        call = dict(ref_image=ref_img, audio_tensor=audio_tensor, face_emb=face_emb, face_mask=face_region,
+                    pixel_values_full_mask=full_mask, pixel_values_face_mask=face_mask,
+                    pixel_values_lip_mask=lip_mask, width=img_size[0], height=img_size[1], video_length=clip_length,
+                    num_inference_steps=inference_steps, guidance_scale=cfg_scale, generator=generator,
+                    motion_scale=motion_scale)
+        if overlap_decode and on_gpu and 0 < n_motion_frames < clip_length:
+            prev, host = _decode_overlapped(pipeline, pipeline(decode=False, **call), clip_length, n_motion_frames, output)
+            results.append(host)
+            if on_clip is not None:
+                on_clip(t, times)
+            continue
+        out = pipeline(**call, **({"output_type": "device"} if on_gpu else {}))
         prev = out.videos
         if output == "uint8" and on_gpu:
             u8 = frames_to_uint8(prev[0])
@@ -85,11 +98,40 @@ def generate_video(pipeline, audioproj, source_image_pixels, source_image_face_r
             on_clip(t, times)
     if on_gpu:
         torch.cuda.current_stream().synchronize()
+        if overlap_decode:
+            pipeline.decode_side[0].synchronize()
     if output == "uint8" and on_gpu:
         return torch.cat(results, dim=0)[:audio_length]
     if output == "uint8":
         raise ops._l.HalloLibraryError("uint8 output runs through hallo_frames_to_uint8 on the GPU; there is no CPU path")
     return torch.cat(results, dim=2).squeeze(0)[:, :audio_length]
+
+
+def _decode_overlapped(pipeline, lat5, clip_length, n_motion, output):
+    """lat5 (1, C, F, h, w) fp32 device latents of a finished clip -> (tail, host): `tail` (1, 3, n_motion, H, W) fp32 on the
+    device = the decoded LAST n_motion frames (the next clip's motion frames; decoded on the current stream), `host` = the
+    pinned host tensor all F frames arrive in (float: (1, 3, F, H, W); uint8: (F, H, W, 3)) once the pipeline's decode stream --
+    which decodes the first F - n_motion frames behind an event, converts and copies -- is synchronised."""
+    _, C, Fr, h, w = lat5.shape
+    L = h * w
+    lat = lat5[0].permute(1, 2, 3, 0).reshape(Fr * L, C).contiguous()
+    nh = Fr - n_motion
+    tail, H, W = pipeline.decode_latents_device(lat[nh * L:], n_motion, h, w)               # [n_motion, 3, H*W] in [0, 1]
+    main = torch.cuda.current_stream()
+    side, scratch = pipeline.decode_side
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        head, _, _ = pipeline.decode_latents_device(lat[:nh * L], nh, h, w, scratch=scratch)
+        frames = torch.cat([head, tail], dim=0)                                                # [F, 3, H*W]
+        if output == "uint8":
+            dev_out = ops.frames_to_uint8(frames).view(Fr, H, W, 3)
+        else:
+            dev_out = frames.view(Fr, 3, H, W).permute(1, 0, 2, 3).unsqueeze(0)
+        host = torch.empty(dev_out.shape, dtype=dev_out.dtype).pin_memory()
+        host.copy_(dev_out, non_blocking=True)
+    for t_ in (lat, tail):
+        t_.record_stream(side)            # allocated on the main stream, read by the decode stream
+    return tail.view(n_motion, 3, H, W).permute(1, 0, 2, 3).unsqueeze(0), host
 
 
 # ------------------------------------------------------------------------------------------------

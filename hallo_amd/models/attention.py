@@ -82,6 +82,7 @@ class _NoCache:
 
 
 NO_CACHE = _NoCache()
+SKIP_BANK = "skip_bank"      # `do_cfg` value of a B = 1 evaluation of the UNCOND half of a CFG pair: no row reads the reference bank
 
 
 class BasicTransformerBlock(nn.Module):
@@ -136,24 +137,33 @@ class TemporalBasicTransformerBlock(nn.Module):
         self.attn1.fold_norm(self.norm1)
         self.ff.fold_norm(self.norm3)
 
-    def run(self, x, enc, bank, video_length, do_cfg, cache=NO_CACHE):
+    def run(self, x, enc, bank, video_length, do_cfg, cache=NO_CACHE, bank_layout=None):
         """x [n = b*f, L, C]; enc [b, T, Cx] face tokens; bank [b*s, L, C] (s = 1 reference + motion frames,
-        fp16-rounded: ReferenceAttentionControl.update casts to fp16 whatever the run dtype, :404,452)."""
+        fp16-rounded: ReferenceAttentionControl.update casts to fp16 whatever the run dtype, :404,452).
+        bank_layout = (bank batches bb, this call's first batch, its first global frame row row0): the call evaluates a SLICE
+        of the batch (cfg_split: one half of a CFG pair at b = 1) against the bank of the whole batch -- global frame row r
+        reads the reference features of bank batch r % bb whatever batch it belongs to (the tiling rule below)."""
         n, L, Cd = x.shape
         b = n // video_length
+        bb, _, row0 = bank_layout if bank_layout is not None else (b, 0, 0)
         a1 = self.attn1
-
-        def bank_kv():
-            ref = bank.view(b, -1, L, Cd)[:, 0].to(x.dtype)      # d_b[:, 0]: the reference image's features
-            return a1.kv(ref.contiguous())
-        k2, v2 = cache.get(self, "bank_kv", bank_kv)
-
         _, q, k, v = a1.qkv_ln(x)
-        # K/V = [self ; bank]: frame row r reads bank entry r % b (the reference's `.repeat(1, f, 1, 1)` on the
-        # 3-D tensor tiles the batch axis, mutual_self_attention.py:235-247); with CFG the first half of the
-        # rows (uncond) skips the bank segment (:264-284).
-        a = ops.attention(q, k, v, a1.heads, k2=k2, v2=v2, kv2_batch_div=1, kv2_batch_mod=b,
-                          kv2_first_batch=(n // 2 if do_cfg else 0), q_prescaled=True)
+        if do_cfg == SKIP_BANK:
+            # the uncond half of a CFG evaluation run on its own (FaceAnimatePipeline(cfg_split=True)): its rows attend to
+            # themselves only (mutual_self_attention.py:264-284), the bank segment does not exist for this call
+            a = ops.attention(q, k, v, a1.heads, q_prescaled=True)
+        else:
+            def bank_kv():
+                ref = bank.view(bb, -1, L, Cd)[:, 0].to(x.dtype)     # d_b[:, 0]: the reference image's features
+                if row0 % bb:
+                    ref = ref.roll(-(row0 % bb), 0)                  # local row j is global row row0 + j
+                return a1.kv(ref.contiguous())
+            k2, v2 = cache.get(self, "bank_kv", bank_kv)
+            # K/V = [self ; bank]: frame row r reads bank entry r % b (the reference's `.repeat(1, f, 1, 1)` on the
+            # 3-D tensor tiles the batch axis, mutual_self_attention.py:235-247); with CFG the first half of the
+            # rows (uncond) skips the bank segment (:264-284).
+            a = ops.attention(q, k, v, a1.heads, k2=k2, v2=v2, kv2_batch_div=1, kv2_batch_mod=bb,
+                              kv2_first_batch=(n // 2 if do_cfg else 0), q_prescaled=True)
         x = a1.out(a, residual=x)
 
         a2 = self.attn2

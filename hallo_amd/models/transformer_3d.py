@@ -28,11 +28,11 @@ class Transformer3DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([blk])
         self.proj_out = Conv1x1(inner, in_channels)
 
-    def run_spatial(self, x, enc, bank, video_length, do_cfg, cache=NO_CACHE):
+    def run_spatial(self, x, enc, bank, video_length, do_cfg, cache=NO_CACHE, bank_layout=None):
         n, L, Cd = x.shape
         h = self.norm.run(x)
         h = self.proj_in.run(h.view(n * L, Cd)).view(n, L, self.inner)
-        h = self.transformer_blocks[0].run(h, enc, bank, video_length, do_cfg, cache)
+        h = self.transformer_blocks[0].run(h, enc, bank, video_length, do_cfg, cache, bank_layout)
         return self.proj_out.run(h.view(n * L, self.inner), residual=x.view(n * L, Cd)).view(n, L, Cd)
 
     def run_audio(self, x, audio, masks, motion_scale, cache=NO_CACHE, out=None):

@@ -203,11 +203,16 @@ class UNet3DConditionModel(HalloModule):
 
     # ---------------------------------------------------------------- execution (token-major API)
     def forward_tokens(self, x, timestep, enc, banks, audio, mask_cond, masks, motion_scale, batch, frames, H, W,
-                       do_cfg, cache=NO_CACHE):
+                       do_cfg, cache=NO_CACHE, out=None, bank_layout=None):
         """One denoising evaluation.
         x [batch*frames, H*W, 8] (4 latent channels, zero-padded to 8); enc [batch, T, Cx];
         banks: 16 tensors [batch*3, hw_l, C_l]; audio [batch*frames, 32, Ca];
         mask_cond [batch*frames, H*W, C0] or None; masks[depth] = (full, face, lip) fp32 [batch*frames, hw_depth].
+        do_cfg: False (every row reads the bank), True (rows of the first half of the batch -- uncond -- skip it), or
+        models.attention.SKIP_BANK (no row reads it: the uncond half evaluated on its own at batch 1).
+        bank_layout: (bank batches, this call's first batch, its first global frame row) when `banks` belong to a larger batch
+        than this call evaluates (one half of a CFG pair: FaceAnimatePipeline(cfg_split=True)).
+        out: optional [batch*frames, H*W, out_channels] buffer (row-contiguous view) the last convolution writes into.
         Returns [batch*frames, H*W, out_channels]."""
         self.prepare()
         n = batch * frames
@@ -215,7 +220,7 @@ class UNet3DConditionModel(HalloModule):
         t_emb = ops.timestep_embedding(t, self.config.block_out_channels[0], x.dtype)
         semb = self.time_embedding.run_silu(t_emb)
         temb_all = ops.gemm(semb, self.w_temb_all, self.b_temb_all)
-        st = StepState(batch, frames, do_cfg, enc, banks, audio, masks, motion_scale, cache, temb_all)
+        st = StepState(batch, frames, do_cfg, enc, banks, audio, masks, motion_scale, cache, temb_all, bank_layout)
 
         x = self.conv_in.run(x, n, H, W, residual=mask_cond)
         skips = [(x, H, W)]
@@ -226,7 +231,7 @@ class UNet3DConditionModel(HalloModule):
         for blk in self.up_blocks:
             x, H, W = blk.run(st, x, H, W, skips)
         x = self.conv_norm_out.run(x, silu=True)
-        return self.conv_out.run(x, n, H, W)
+        return self.conv_out.run(x, n, H, W, out=out)
 
     # ---------------------------------------------------------------- execution (reference API, NCHW)
     @torch.no_grad()

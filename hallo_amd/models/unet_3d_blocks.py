@@ -28,8 +28,11 @@ from .transformer_3d import Transformer3DModel
 class StepState:
     """Per-call state shared by the blocks of one UNet evaluation."""
 
-    def __init__(self, batch, frames, do_cfg, enc, banks, audio, masks, motion_scale, cache, temb_all):
+    def __init__(self, batch, frames, do_cfg, enc, banks, audio, masks, motion_scale, cache, temb_all, bank_layout=None):
         self.batch, self.frames, self.do_cfg = batch, frames, do_cfg
+        # (bank batches, first batch of this call, first global frame row): the banks of a WHOLE CFG batch handed to an
+        # evaluation of one of its halves (models/attention.py TemporalBasicTransformerBlock.run)
+        self.bank_layout = bank_layout
         self.enc, self.audio, self.masks, self.motion_scale = enc, audio, masks, motion_scale
         self.cache = cache
         self.temb_all = temb_all
@@ -66,12 +69,15 @@ def _layer(st, x, H, W, attn, audio, motion, depth):
     B, F = st.batch, st.frames
     n, L, Cd = x.shape
     bank = st.next_bank()
-    x = attn.run_spatial(x, st.enc, bank, F, st.do_cfg, st.cache)
+    x = attn.run_spatial(x, st.enc, bank, F, st.do_cfg, st.cache, st.bank_layout)
     if audio is None and motion is None:        # stage-1 configuration
         return x
 
     # motion-frame features = bank[:, 1:] (mutual_self_attention.py:327), cast once per clip
     def mf_make():
+        if st.bank_layout is not None:
+            bb, b0, _ = st.bank_layout
+            return bank.view(bb, -1, L, Cd)[b0:b0 + B, 1:].to(x.dtype).contiguous()
         return bank.view(B, -1, L, Cd)[:, 1:].to(x.dtype).contiguous()
     mf = st.cache.get(motion, "motion_frames", mf_make)
     nm = mf.shape[1]

@@ -512,7 +512,7 @@ def _traj_oracle(name):
     return _CACHE[key]
 
 
-@pytest.mark.parametrize("routing", ["throughput", "latency"])
+@pytest.mark.parametrize("routing", ["throughput", "latency", "latency+cfg_split"])
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("name", list(TRAJ))
 def test_full_pipeline_trajectory(dtype, name, routing, report):
@@ -527,6 +527,12 @@ def test_full_pipeline_trajectory(dtype, name, routing, report):
     from hallo_amd.animate.face_animate import FaceAnimatePipeline
     from hallo_amd.scheduler import DDIMScheduler
     c = _traj_cfg(name)
+    # "+cfg_split" (round 5): the uncond / cond halves of every evaluation as two B = 1 graphs on two streams (the sequential
+    # video path's overlap, FaceAnimatePipeline(cfg_split=True)) -- only the CFG trajectory has halves
+    cfg_split = routing.endswith("+cfg_split")
+    if cfg_split and c["gs"] <= 1.0:
+        pytest.skip("cfg_split only changes the CFG path")
+    routing_name, routing = routing, routing.split("+")[0]
     d, args, lat, _ = _traj_inputs(name)
     ref = _traj_oracle(name)
     n = _native(dtype)
@@ -535,7 +541,7 @@ def test_full_pipeline_trajectory(dtype, name, routing, report):
     graph = DEV != "cpu"
     pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
                                face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched, use_graph=graph,
-                               routing=routing)
+                               routing=routing, cfg_split=cfg_split)
     seen = []
     before = ops.options_fingerprint()
     try:
@@ -543,7 +549,10 @@ def test_full_pipeline_trajectory(dtype, name, routing, report):
                      callback=lambda i, t, l: seen.append((int(t), l.float().cpu() if i + 1 in c["keep"] else None))).videos
         if graph:
             (sg,) = pipe._graphs.values()
-            assert sg.graph is not None and sg.replays == c["steps"] - 1
+            if cfg_split:
+                assert sg.graph is None and all(h.graph is not None and h.replays == c["steps"] - 1 for h in sg.halves)
+            else:
+                assert sg.graph is not None and sg.replays == c["steps"] - 1
             if routing == "throughput" and ARCH == "full":
                 with ops.routing(pipe.routing):
                     assert ops.get_option("ff_fused") == 1 and ops.get_option("gemm_rs") == 0
@@ -558,13 +567,13 @@ def test_full_pipeline_trajectory(dtype, name, routing, report):
     per_step_max = [float((a.float() - b.float()).abs().max() / b.float().pow(2).mean().sqrt()) for a, b in zip(kept, ref["latents"])]
     _rec(report, f"full_{name}_latents[{c['S']}x{c['S']}x{c['Fr']}f,{c['steps']} steps,gs={c['gs']}]", dtype, max(per_step), 5e-2,
          steps_kept=c["keep"], per_step=[round(v, 6) for v in per_step], max_abs_over_rms=[round(v, 5) for v in per_step_max],
-         oracle=ref["oracle"], launch="hipGraph replay" if graph else "eager", kernel_routing=routing)
+         oracle=ref["oracle"], launch="hipGraph replay" if graph else "eager", kernel_routing=routing_name)
     assert max(per_step_max) <= 0.5, per_step_max       # no single latent value off by half an RMS (a corrupted tile would be)
     assert max(per_step) <= 5e-2, per_step
     assert vid_n.shape == (1, 3, c["Fr"], c["S"], c["S"])
     p = Hn.psnr(vid_n[:, :, c["frames"]], ref["video"])
     report.append({"test": f"full_{name}_frames_psnr[{c['S']}x{c['S']}x{c['Fr']}f,{c['steps']} steps,gs={c['gs']}]", "dtype": str(dtype),
-                   "arch": ARCH, "psnr_db": p, "tol_psnr_db": 35.0, "frames_compared": c["frames"], "kernel_routing": routing})
+                   "arch": ARCH, "psnr_db": p, "tol_psnr_db": 35.0, "frames_compared": c["frames"], "kernel_routing": routing_name})
     print("PSNR", p)
     assert p >= 35.0
 

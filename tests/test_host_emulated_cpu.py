@@ -90,16 +90,21 @@ def test_conditioners_and_vae(emu, oracle):
         assert Hn.rel_l2(n["vae"].decode(z).sample, o["vae"].decode(z).sample) < TOL
 
 
+@pytest.mark.parametrize("cfg_split", [False, True])
 @pytest.mark.parametrize("guidance", [3.5, 1.0])
-def test_pipeline_end_to_end(emu, oracle, guidance):
+def test_pipeline_end_to_end(emu, oracle, guidance, cfg_split):
     """FaceAnimatePipeline.__call__ vs oracle.hallo_ref.animate: 64x64, 2 frames, 2 DDIM steps, per-step latents, schedule
-    indices and decoded frames."""
+    indices and decoded frames.  cfg_split (round 5): the uncond / cond halves of every CFG evaluation as two B = 1
+    evaluations (bank rows 0..2 / 3..5, no bank segment for the uncond half, halves of one output buffer) -- the same numbers."""
+    if cfg_split and guidance <= 1.0:
+        pytest.skip("cfg_split only changes the CFG path")
+    Fr_case = 3 if cfg_split else 2        # odd frame count: the cond half starts on an odd global row (bank roll)
     from oracle import harness as Hn
     from oracle import hallo_ref as H
     from hallo_amd.animate.face_animate import FaceAnimatePipeline
     from hallo_amd.scheduler import DDIMScheduler
     o, n = oracle, _native(oracle)
-    S, Fr, steps = 64, 2, 2
+    S, Fr, steps = 64, Fr_case, 2
     d = Hn.clip_inputs(S, Fr)
     args = (d["ref_image"], d["face_emb"], d["audio"], d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr, steps, guidance)
     seen_o, seen_n = [], []
@@ -110,7 +115,7 @@ def test_pipeline_end_to_end(emu, oracle, guidance):
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
                           prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
     pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
-                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched)
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched, cfg_split=cfg_split)
     vid_n = pipe(*args, motion_scale=d["motion_scale"], latents=d["latents"],
                  callback=lambda i, t, l: seen_n.append((int(t), l.float().clone()))).videos
     assert [t for t, _ in seen_n] == [t for t, _ in seen_o] == [999, 499]

@@ -132,10 +132,13 @@ def test_vae(nets, report):
         assert v <= tol
 
 
+@pytest.mark.parametrize("cfg_split", [False, True], ids=["batched", "cfg_split"])
 @pytest.mark.parametrize("guidance", [3.5, 1.0])
-def test_pipeline_end_to_end(nets, guidance, report):
+def test_pipeline_end_to_end(nets, guidance, cfg_split, report):
     """FaceAnimatePipeline.__call__ vs oracle.hallo_ref.animate: 128x128, 4 frames, 4 DDIM steps; per-step
     latents, schedule indices (bit-exact) and decoded frames."""
+    if cfg_split and guidance <= 1.0:
+        pytest.skip("cfg_split only changes the CFG path")
     dtype, o, n = nets
     from oracle import harness as Hn
     from oracle import hallo_ref as H
@@ -153,17 +156,17 @@ def test_pipeline_end_to_end(nets, guidance, report):
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
                           prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
     pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
-                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched)
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched, cfg_split=cfg_split)
     vid_n = pipe(*args, motion_scale=d["motion_scale"], latents=rd(d["latents"]),
                  callback=lambda i, t, l: seen_n.append((int(t), l.float().cpu()))).videos
     assert [t for t, _ in seen_n] == [t for t, _ in seen_o] == [999, 749, 499, 249]
     worst = max(Hn.rel_l2(a, b) for (_, a), (_, b) in zip(seen_n, seen_o))
-    _rec(report, f"pipeline_latents[gs={guidance}]", dtype, worst, 5e-2)
+    _rec(report, f"pipeline_latents[gs={guidance}{',cfg_split' if cfg_split else ''}]", dtype, worst, 5e-2)
     assert worst <= 5e-2
     assert vid_n.shape == vid_o.shape == (1, 3, Fr, S, S) and vid_n.dtype == torch.float32
     assert float(vid_n.min()) >= 0.0 and float(vid_n.max()) <= 1.0
     p = Hn.psnr(vid_n, vid_o)
-    report.append({"test": f"pipeline_frames_psnr[gs={guidance}]", "dtype": str(dtype), "psnr_db": p, "tol_psnr_db": 35.0})
+    report.append({"test": f"pipeline_frames_psnr[gs={guidance}{',cfg_split' if cfg_split else ''}]", "dtype": str(dtype), "psnr_db": p, "tol_psnr_db": 35.0})
     print("PSNR", p)
     assert p >= 35.0
 
@@ -198,6 +201,44 @@ def test_pipeline_hipgraph_replay_is_byte_identical(nets, guidance, report):
     (sg,) = graphed._graphs.values()
     assert sg.graph is not None and sg.replays == 3 * (steps - 1)
     report.append({"test": f"pipeline_hipgraph_byte_identical[gs={guidance}]", "dtype": str(dtype), "clips": 3, "replays": sg.replays})
+
+
+def test_pipeline_cfg_split_graph_replay_is_byte_identical(nets, report):
+    """cfg_split=True (round 5): the uncond / cond halves of every CFG evaluation as two B = 1 evaluations on two HIP streams,
+    joined at the fused CFG + DDIM kernel.  With use_graph each half has its own captured graph, clip cache and launch scratch:
+    the frames of three consecutive clips must equal the eager split pipeline's byte for byte, and stay within the storage
+    type's noise of the batched (B = 2) evaluation (other launch shapes -> other split-K / tile routing, not other maths)."""
+    dtype, o, n = nets
+    from oracle import harness as Hn
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.scheduler import DDIMScheduler
+    S, Fr, steps, gs = 128, 4, 4, 3.5
+    mk = lambda: DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                               prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    kw = dict(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+              face_locator=n["face_locator"], image_proj=n["imageproj"])
+    batched = FaceAnimatePipeline(scheduler=mk(), **kw)
+    eager = FaceAnimatePipeline(scheduler=mk(), cfg_split=True, **kw)
+    graphed = FaceAnimatePipeline(scheduler=mk(), cfg_split=True, use_graph=True, **kw)
+    rd = lambda t: t.to(dtype).float()
+    worst = 99.0
+    for clip in range(3):
+        d = Hn.clip_inputs(S, Fr, seed=4234 + clip)
+        lat = rd(torch.randn(d["latents"].shape, generator=torch.Generator().manual_seed(142 + clip)))
+        args = (rd(d["ref_image"]), rd(d["face_emb"]), rd(d["audio"]), d["face_mask"], [rd(m) for m in d["full"]],
+                [rd(m) for m in d["face"]], [rd(m) for m in d["lip"]], S, S, Fr, steps, gs)
+        ms = [1.0, 0.8, 1.2]
+        a = eager(*args, motion_scale=ms, latents=lat).videos
+        b = graphed(*args, motion_scale=ms, latents=lat).videos
+        c = batched(*args, motion_scale=ms, latents=lat).videos
+        assert torch.equal(a, b), (clip, (a - b).abs().max().item())
+        worst = min(worst, Hn.psnr(a, c))
+    (sg,) = graphed._graphs.values()
+    assert sg.graph is None and all(h.graph is not None and h.replays == 3 * (steps - 1) for h in sg.halves)
+    assert graphed.scratch.splitk.data_ptr() != graphed.scratch_aux.splitk.data_ptr()
+    assert worst >= 40.0, worst
+    graphed.reset_graphs()
+    report.append({"test": "pipeline_cfg_split_graph_byte_identical", "dtype": str(dtype), "clips": 3, "psnr_vs_batched_db": worst})
 
 
 def test_pipeline_hipgraph_survives_reload_and_option_change(nets, report):
@@ -387,3 +428,16 @@ def test_sliding_window_driver(nets, report):
     assert u8.shape == (7, S, S, 3) and u8.dtype == torch.uint8
     # (two separate runs of the same seed: every kernel on the path is bit-reproducible, so the bytes are identical)
     assert torch.equal(u8, torch.from_numpy(D.frames_to_uint8(vn)))
+    # round 5: the same video with the sequential-path overlaps on -- cond / uncond halves on two streams (cfg_split), the last two
+    # frames of a clip decoded first and the other frames decoded / converted / copied underneath the next clip (overlap_decode)
+    pipe2 = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+                                face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched, cfg_split=True, use_graph=True)
+    vs = V.generate_video(pipe2, *args[1:], output="float", overlap_decode=True, **kw)
+    assert vs.shape == vo.shape and not vs.is_cuda
+    q1, q2 = Hn.psnr(vs[:, :Fr], vo[:, :Fr]), Hn.psnr(vs[:, Fr:], vo[:, Fr:])
+    report.append({"test": "sliding_window_psnr[cfg_split,overlap_decode,graph]", "dtype": str(dtype), "psnr_clip1_db": q1, "psnr_clip2_db": q2,
+                   "tol_psnr_db": 35.0, "tol_psnr_clip2_db": 30.0})
+    assert q1 >= 35.0 and q2 >= 30.0
+    us = V.generate_video(pipe2, *args[1:], output="uint8", overlap_decode=True, **kw)
+    assert torch.equal(us, torch.from_numpy(D.frames_to_uint8(vs)))
+    pipe2.reset_graphs()
