@@ -33,6 +33,11 @@ import time
 
 # the host driver of the GPU pool only supports dmabuf IPC: RCCL's cross-process buffer sharing needs this (N > 1)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# One clip is ~19 500 AQL packets (3 000 eager launches + 24 graph replays x 690 kernels); the HIP runtime's default hardware queue holds
+# 16 384, so the launch thread spun inside enqueue calls against a full queue for most of every clip.  With a queue that holds three clips
+# it enqueues and goes to sleep on the slot's blocking event: process CPU 1.68 -> 1.40 cores per rank, frames/s +1 % (profiles/
+# r5_host_aql_queue.json).  Read by the runtime at first use: must be set before HIP initialises.
+os.environ.setdefault("ROC_AQL_QUEUE_SIZE", "65536")
 
 import torch  # noqa: E402
 

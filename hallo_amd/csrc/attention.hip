@@ -796,7 +796,10 @@ __global__ __launch_bounds__(256) void temporal_attn_tiled_kernel(const T* __res
 //     scale) and written over the head's own Q columns of the tile, and the tile leaves by whole-line 16-byte stores.
 // q must be pre-scaled (head_dim^-1/2 * log2 e), as everything on the UNet path is.
 // -------------------------------------------------------------------------------------------
-template <typename T, int HD>
+// PF (round 5): the NEXT query tile's global loads are issued right after this tile went to LDS, so they fly under the MFMA /
+// softmax work of the current tile instead of opening the next iteration (a workgroup walks 1..8 tiles; the chain load -> LDS ->
+// compute -> store per tile was fully serial inside a workgroup, hidden only by the 3 workgroups a CU holds).
+template <typename T, int HD, bool PF>
 __global__ __launch_bounds__(HD == 160 ? 128 : 256) void tok_attn_kernel(const AttnArgs p, int groups, int parts, int ntiles) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
@@ -845,21 +848,27 @@ __global__ __launch_bounds__(HD == 160 ? 128 : 256) void tok_attn_kernel(const A
   }
   const int gi = lane & 15, gdh = (lane >> 4) & 1;
 
+  V8 st[NLD];
+  auto load_tile = [&](int t) {
+    const int r0 = t * 32;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int q = tid + NT * i, r = q / CPR, cc = q - r * CPR;
+      st[i] = ld8<T>(Qg + (long)min(r0 + r, p.Lq - 1) * p.q_rs + cc * 8);
+    }
+  };
+  if (PF && part < ntiles) load_tile(part);
   for (int t = part; t < ntiles; t += parts) {
     const int row0 = t * 32;
     // ---- query tile -> LDS ----
     {
-      V8 st[NLD];
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int q = tid + NT * i, r = q / CPR, cc = q - r * CPR;
-        st[i] = ld8<T>(Qg + (long)min(row0 + r, p.Lq - 1) * p.q_rs + cc * 8);
-      }
+      if (!PF) load_tile(t);
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         const int q = tid + NT * i, r = q / CPR, cc = q - r * CPR;
         *reinterpret_cast<V8*>(tile + r * PITCH + cc * 16) = st[i];
       }
+      if (PF && t + parts < ntiles) load_tile(t + parts);
     }
     __syncthreads();
     const int qrow = min(row0 + l31, p.Lq - 1);
@@ -934,8 +943,12 @@ __global__ __launch_bounds__(HD == 160 ? 128 : 256) void tok_attn_kernel(const A
   }
 }
 
-static int g_tok_attn = 1;        // hallo_set_option("tok_attn", 0 | 1): token cross-attention kernel for K/V of <= 32 rows (A/B)
 static int g_last_attn = 0;       // hallo_get_option("last_attn_kernel"): 1 flash kernel of this file, 2 attention40.hip, 3 tok_attn_kernel
+
+// hallo_set_option("tok_attn", 0 | 1 | 2): 0 flash kernels; 1 token cross-attention kernel for K/V of <= 32 rows (round 3); 2 (default, round 5) the
+// same with the next query tile prefetched where that paid on MI355X (profiles/r5_prefetch_ab.json: workgroups that walk >= 4 tiles -- 64 x 64
+// level, 57.4 -> 55.8 us -- and head dim 160 -- 29.8 -> 28.6 us; with 2 tiles per workgroup the extra 20 registers cost more than the overlap gives)
+static int g_tok_attn = 2;
 
 template <typename T, int HD>
 static int launch_tok_attn_hd(const AttnArgs& a, hipStream_t st) {
@@ -948,7 +961,8 @@ static int launch_tok_attn_hd(const AttnArgs& a, hipStream_t st) {
   int parts = (target + a.batch * groups - 1) / (a.batch * groups);
   if (parts > ntiles) parts = ntiles;
   if (parts < 1) parts = 1;
-  hipLaunchKernelGGL((tok_attn_kernel<T, HD>), dim3((unsigned)(a.batch * groups * parts)), dim3(NT), 0, st, a, groups, parts, ntiles);
+  if (g_tok_attn == 2 && (HD == 160 || ntiles >= 4 * parts)) hipLaunchKernelGGL((tok_attn_kernel<T, HD, true>), dim3((unsigned)(a.batch * groups * parts)), dim3(NT), 0, st, a, groups, parts, ntiles);
+  else hipLaunchKernelGGL((tok_attn_kernel<T, HD, false>), dim3((unsigned)(a.batch * groups * parts)), dim3(NT), 0, st, a, groups, parts, ntiles);
   HALLO_CHECK_LAUNCH();
   return 0;
 }
@@ -1033,7 +1047,7 @@ extern "C" int hallo_set_option_attn(const char* name, int value) {
   if (name && !strcmp(name, "temporal_mfma")) { if (value < 0 || value > 2) return -22; g_temporal_mfma = value; return 0; }
   if (name && !strcmp(name, "attn_order")) { if (value < 0 || value > 2) return -22; g_attn_order = value; return 0; }
   if (name && !strcmp(name, "attn40")) { if (value < 0 || value > 8) return -22; g_attn40 = value; set_attn40_variant(value); return 0; }
-  if (name && !strcmp(name, "tok_attn")) { if (value < 0 || value > 1) return -22; g_tok_attn = value; return 0; }
+  if (name && !strcmp(name, "tok_attn")) { if (value < 0 || value > 2) return -22; g_tok_attn = value; return 0; }
   if (name && !strcmp(name, "xattn_tiled")) return hallo_set_option_xattn(name, value);     // fused_xattn.hip
   return -22;
 }

@@ -153,8 +153,9 @@ __global__ __launch_bounds__(256) void face_xattn_kernel(const XattnArgs p) {
 // k slices and channel blocks are dealt to the 4 waves exactly as above and partial sums are combined in the same order, so the
 // two kernels agree bit for bit (tests/test_ops_gpu.py compares them).
 // ------------------------------------------------------------------------------------------------------------------------
-template <typename T, int C>
-__global__ __launch_bounds__(256, C == 320 ? 3 : (C == 640 ? 2 : 1)) void face_xattn_tiled_kernel(const XattnArgs p, int nblocks) {
+// PF (round 5): the next block's x loads are issued right after this block went to LDS and fly under its MFMA / softmax work.
+template <typename T, int C, bool PF>
+__global__ __launch_bounds__(256, C == 320 ? (PF ? 2 : 3) : (C == 640 ? 2 : 1)) void face_xattn_tiled_kernel(const XattnArgs p, int nblocks) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   constexpr int PITCH = C * 2 + 16;              // bytes
@@ -175,6 +176,17 @@ __global__ __launch_bounds__(256, C == 320 ? 3 : (C == 640 ? 2 : 1)) void face_x
   V8 ow0[NCW], ow1[NCW];     // OwP[c = cb * 32 + l31][hi * 8 ..] and [16 + hi * 8 ..], cb = wave + 4 j
   __shared__ float s_gb[2][32];                                // G / B of the current batch (LDS: 32 registers fewer than copies per lane)
   long cur_b = -1;
+  V8 st[NLD];
+  auto load_block = [&](int blk_) {
+    const T* xb = reinterpret_cast<const T*>(p.x);
+    const long r0 = (long)blk_ * 32;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int q = tid + 256 * i, r = q / CPR, cc = q - r * CPR;
+      st[i] = ld8<T>(xb + min(r0 + r, p.rows - 1) * C + cc * 8);
+    }
+  };
+  if (PF && (int)blockIdx.x < nblocks) load_block(blockIdx.x);
 
   for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const long row0 = (long)blk * 32;
@@ -200,18 +212,13 @@ __global__ __launch_bounds__(256, C == 320 ? 3 : (C == 640 ? 2 : 1)) void face_x
 
     // ---- 1. x block -> LDS ----
     {
-      const T* xb = reinterpret_cast<const T*>(p.x);
-      V8 st[NLD];
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int q = tid + 256 * i, r = q / CPR, cc = q - r * CPR;
-        st[i] = ld8<T>(xb + min(row0 + r, p.rows - 1) * C + cc * 8);
-      }
+      if (!PF) load_block(blk);
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
         const int q = tid + 256 * i, r = q / CPR, cc = q - r * CPR;
         *reinterpret_cast<V8*>(tile + r * PITCH + cc * 16) = st[i];
       }
+      if (PF && blk + (int)gridDim.x < nblocks) load_block(blk + gridDim.x);
     }
     __syncthreads();
 
@@ -295,9 +302,11 @@ __global__ __launch_bounds__(256, C == 320 ? 3 : (C == 640 ? 2 : 1)) void face_x
 
 using namespace hallo;
 
-static int g_xattn_tiled = 1;    // hallo_set_option("xattn_tiled", 0 | 1): LDS-staged face cross-attention for C = 320 / 640 / 1280 (A/B)
+// hallo_set_option("xattn_tiled", 0 | 1 | 2): LDS-staged face cross-attention for C = 320 / 640 / 1280; 2 (default, round 5): next-block prefetch at
+// C = 320 (65536 rows: 29.8-32.0 -> 24.5-25.6 us, 73728 rows: 31.8 -> 26.4; profiles/r5_prefetch_ab.json)
+static int g_xattn_tiled = 2;
 extern "C" int hallo_set_option_xattn(const char* name, int value) {
-  if (name && !strcmp(name, "xattn_tiled")) { if (value < 0 || value > 1) return -22; g_xattn_tiled = value; return 0; }
+  if (name && !strcmp(name, "xattn_tiled")) { if (value < 0 || value > 2) return -22; g_xattn_tiled = value; return 0; }
   return -2;
 }
 
@@ -321,7 +330,10 @@ extern "C" int hallo_face_xattn(const void* x, void* y, const void* sg, const fl
     const int nblocks = (int)grid.x;
     const int cap = C == 320 ? 768 : 512;             // resident workgroups: 3 per CU at C = 320 (160 registers, 39 KB), 2 at 640, 1 at 1280
     const dim3 pg((unsigned)(nblocks < cap ? nblocks : cap));
-#define HALLO_XT(TT, CC) hipLaunchKernelGGL((face_xattn_tiled_kernel<TT, CC>), pg, block, 0, st, a, nblocks)
+    // the prefetching form only where a workgroup walks several blocks (C = 320 at 64 x 64: 2048 blocks over <= 512 workgroups of
+    // 226 registers, two per SIMD); at C = 640 / 1280 every workgroup has one block and the extra registers would spill
+#define HALLO_XT(TT, CC) do { if (g_xattn_tiled == 2 && CC == 320) hipLaunchKernelGGL((face_xattn_tiled_kernel<TT, 320, true>), dim3((unsigned)(nblocks < 512 ? nblocks : 512)), block, 0, st, a, nblocks); \
+                              else hipLaunchKernelGGL((face_xattn_tiled_kernel<TT, CC, false>), pg, block, 0, st, a, nblocks); } while (0)
     if (dtype == DT_F16) { if (C == 320) HALLO_XT(_Float16, 320); else if (C == 640) HALLO_XT(_Float16, 640); else HALLO_XT(_Float16, 1280); }
     else { if (C == 320) HALLO_XT(__bf16, 320); else if (C == 640) HALLO_XT(__bf16, 640); else HALLO_XT(__bf16, 1280); }
 #undef HALLO_XT
