@@ -63,7 +63,7 @@ class OpProfiler:
             s.record()
             r = fn(*a, **k)
             e.record()
-            fl, by = cost(a, k, r)
+            fl, by = cost(a, k, r[0] if isinstance(r, tuple) else r)        # (out, row statistics) from the producers of LayerNorm inputs
             shp = tuple(tuple(t.shape) for t in a[:3] if torch.is_tensor(t)) + ((("geglu",),) if k.get("geglu") else ()) \
                 + ((("res",),) if k.get("residual") is not None else ()) + ((("k2", tuple(k["k2"].shape)),) if k.get("k2") is not None else ())
             sym = self._symbol(name, a, k)

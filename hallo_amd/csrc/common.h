@@ -104,6 +104,15 @@ __device__ __forceinline__ float gelu_u(float u) {
   return __builtin_fmaf(-au, (q * t) * e, fmaxf(u, 0.0f));
 }
 
+// Sum over each aligned group of 8 lanes, result in all 8 (a fixed tree: neighbours, pairs, the two quads): three DPP moves, no
+// LDS permute and no address registers -- the row-statistics epilogues run at the 128-VGPR boundary of the 128 x 128 GEMM kernel.
+__device__ __forceinline__ float sum8_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror: lane i <-> 7 - i
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

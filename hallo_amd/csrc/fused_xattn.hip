@@ -36,6 +36,8 @@ struct XattnArgs {
   int C;
   long rows_per_batch;
   float eps;
+  float* stats_out;      // optional [rows][2] fp32: (mean, rstd) of the OUTPUT rows, eps = stats_eps (the next nn.LayerNorm's statistics)
+  float stats_eps;
 };
 
 template <typename T>
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(256, C == 320 ? (PF ? 2 : 3) : (C == 640 ? 2 : 1)) 
   V8 sgf[NKW];               // Sg[(h,t) = l31][ks * 16 + hi * 8 ..], ks = wave + 4 j
   V8 ow0[NCW], ow1[NCW];     // OwP[c = cb * 32 + l31][hi * 8 ..] and [16 + hi * 8 ..], cb = wave + 4 j
   __shared__ float s_gb[2][32];                                // G / B of the current batch (LDS: 32 registers fewer than copies per lane)
+  __shared__ float s_ostat[4][2][64];                          // stats_out: per-wave partial (sum, sum of squares) of the output rows
   long cur_b = -1;
   V8 st[NLD];
   auto load_block = [&](int blk_) {
@@ -264,6 +267,7 @@ __global__ __launch_bounds__(256, C == 320 ? (PF ? 2 : 3) : (C == 640 ? 2 : 1)) 
       for (int jj = 0; jj < 4; ++jj) pf[g >> 1][(g & 1) * 4 + jj] = from_f32<T>(e4[jj] * inv);
     }
     unsigned char* yrow = tile + l31 * PITCH;
+    float e_s = 0.0f, e_q = 0.0f;      // stats_out: this lane's share of its row's (sum, sum of squares) of the ROUNDED outputs
 #pragma unroll
     for (int j = 0; j < NCW; ++j) {
       const int cb = wave + 4 * j;
@@ -277,12 +281,28 @@ __global__ __launch_bounds__(256, C == 320 ? (PF ? 2 : 3) : (C == 640 ? 2 : 1)) 
           const V4 bb = *reinterpret_cast<const V4*>(bo + c);
           V4 out;
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) out[jj] = from_f32<T>(o[4 * g + jj] + to_f32(bb[jj]) + to_f32(res[jj]));
+          for (int jj = 0; jj < 4; ++jj) {
+            out[jj] = from_f32<T>(o[4 * g + jj] + to_f32(bb[jj]) + to_f32(res[jj]));
+            const float f = to_f32(out[jj]);
+            e_s += f; e_q = __builtin_fmaf(f, f, e_q);
+          }
           *reinterpret_cast<V4*>(yrow + c * 2) = out;
         }
       }
     }
+    if (p.stats_out) { s_ostat[wave][0][lane] = e_s; s_ostat[wave][1][lane] = e_q; }
     __syncthreads();
+    if (p.stats_out && tid < 32 && row0 + tid < p.rows) {
+      // row tid: both halves (lanes tid, tid + 32) of the four waves, in a fixed order
+      float sm = 0.0f, sq2 = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        sm += s_ostat[w][0][tid] + s_ostat[w][0][tid + 32];
+        sq2 += s_ostat[w][1][tid] + s_ostat[w][1][tid + 32];
+      }
+      const float om = sm / (float)C;
+      *reinterpret_cast<float2*>(p.stats_out + 2 * (row0 + tid)) = float2{om, rsqrtf(fmaxf(sq2 / (float)C - om * om, 0.0f) + p.stats_eps)};
+    }
 
     // ---- 4. tile -> y ----
     {
@@ -315,14 +335,17 @@ extern "C" int hallo_get_option_xattn(const char* name) {
   return -22;
 }
 
-extern "C" int hallo_face_xattn(const void* x, void* y, const void* sg, const float* g, const float* b, const void* owp,
-                                const void* bo, int64_t rows, int C, int64_t rows_per_batch, float eps, int dtype,
-                                void* stream) {
+extern "C" int hallo_row_stats(const void* x, float* stats, int64_t rows, int C, float eps, int dtype, void* stream);   // norm_elementwise.hip
+
+extern "C" int hallo_face_xattn_stats(const void* x, void* y, const void* sg, const float* g, const float* b, const void* owp,
+                                      const void* bo, int64_t rows, int C, int64_t rows_per_batch, float eps, float* stats_out,
+                                      float stats_eps, int dtype, void* stream) {
   if (!x || !y || !sg || !g || !b || !owp || !bo || rows <= 0 || C <= 0 || (C & 31)) return -22;
   if (rows_per_batch <= 0 || (rows_per_batch & 31)) return -22;
   XattnArgs a;
   a.x = x; a.y = y; a.sg = sg; a.g = g; a.b = b; a.owp = owp; a.bo = bo;
   a.rows = rows; a.C = C; a.rows_per_batch = rows_per_batch; a.eps = eps;
+  a.stats_out = stats_out; a.stats_eps = stats_eps;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((unsigned)((rows + 31) / 32)), block(256);
   if (g_xattn_tiled && (C == 320 || C == 640 || C == 1280) && (dtype == DT_F16 || dtype == DT_BF16)) {
@@ -344,5 +367,12 @@ extern "C" int hallo_face_xattn(const void* x, void* y, const void* sg, const fl
   else if (dtype == DT_BF16) hipLaunchKernelGGL((face_xattn_kernel<__bf16>), grid, block, 0, st, a);
   else return -22;
   HALLO_CHECK_LAUNCH();
+  if (stats_out) return hallo_row_stats(y, stats_out, rows, C, stats_eps, dtype, stream);     // the untiled kernel does not emit: one pass over y
   return 0;
+}
+
+extern "C" int hallo_face_xattn(const void* x, void* y, const void* sg, const float* g, const float* b, const void* owp,
+                                const void* bo, int64_t rows, int C, int64_t rows_per_batch, float eps, int dtype,
+                                void* stream) {
+  return hallo_face_xattn_stats(x, y, sg, g, b, owp, bo, rows, C, rows_per_batch, eps, nullptr, 0.0f, dtype, stream);
 }

@@ -248,6 +248,21 @@ __device__ uint4 g_zero_page[2];
 
 constexpr int TILE_ELEMS = 128 * 64;
 
+// (sum, sum of squares) of 8 storage-type values added to (s, q): packed dot products with fp32 accumulation (v_dot2c_f32_*), no
+// conversions -- the same four steps in the same order wherever row statistics of ROUNDED outputs are taken (EMIT epilogue of
+// gemm2_kernel, row_parts_kernel), so that both give the same bits.
+template <typename T>
+__device__ __forceinline__ void row_sums8(typename Vec<T>::v8 w, float& s, float& q) {
+  typedef __attribute__((ext_vector_type(2))) T V2t;
+  const V2t one2 = {from_f32<T>(1.0f), from_f32<T>(1.0f)};
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const V2t x2 = {w[e], w[e + 1]};
+    s = dot2(x2, one2, s);
+    q = dot2(x2, x2, q);
+  }
+}
+
 // LNF: LayerNorm fused into the GEMM (see GemmArgs::ln_colsum).  The A fragments that feed the MFMAs are also
 // reduced to per-row sum / sum of squares with packed dot2 instructions (16 VALU ops per 16-deep slice and lane, in the
 // shadow of 4 MFMAs), so nn.LayerNorm costs no pass over HBM at all; the epilogue applies
@@ -257,14 +272,23 @@ constexpr int TILE_ELEMS = 128 * 64;
 // (hallo_row_stats: one read pass over A) -- cheaper whenever several N tiles share a row block, because every tile
 // would otherwise redo the statistics of the same rows (measured: the in-loop form makes the N = 2560 GEGLU GEMMs
 // 25 % slower, more than the LayerNorm launch it replaces).
-template <typename T, int MODE /*0 gemm, 1 conv3x3, 2 geglu, 3 gemm with a GELU epilogue*/, int STAGES, int LNF>
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 || MODE == 3 ? 3 : 4)) void gemm2_kernel(const GemmArgs p) {
+// EMIT (round 5, MODE 0 / LNF 0 only): the epilogue also writes GemmArgs::row_parts -- (sum, sum of squares) of the ROUNDED
+// output values of every row over this wave's 64 columns, slot (n0 + 64 wn) / 64 of [M][ceil(N / 64)][2] -- so that an
+// nn.LayerNorm over C's rows (the next projection's LNF = 2 epilogue) needs no pass over C (hallo_row_stats): 8 lanes hold a
+// row's 64 columns in the read phase, sum8_dpp reduces them.  A separate instantiation: the plain kernel sits at
+// the 128-VGPR boundary.
+// LNF = 2 with GemmArgs::ln_parts > 0: ln_stats holds such partial sums over the K columns of A; behind the K loop the tile's rows
+// are staged through the idle LDS and reduced to (mean, rstd) per row in slot order (deterministic).
+template <typename T, int MODE /*0 gemm, 1 conv3x3, 2 geglu, 3 gemm with a GELU epilogue*/, int STAGES, int LNF, int EMIT = 0>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 || MODE == 3 || EMIT == 2 ? 3 : 4)) void gemm2_kernel(const GemmArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
+  static_assert(!EMIT || (MODE == 0 && LNF == 0), "row_parts emission: plain GEMM epilogue only");
   // MODE 3 is a separate instantiation so that the erf polynomial's registers never burden the hot MODE 0 kernel
   // (it sits exactly at the 128-VGPR / 4-waves-per-SIMD boundary)
   constexpr bool CONV = MODE == 1, GEGLU = MODE == 2, GELU = MODE == 3;
   __shared__ __attribute__((aligned(16))) T smem[STAGES * 2 * TILE_ELEMS];
+  __shared__ float s_ln[LNF == 2 ? 2 * BM : 2];     // (mean, rstd) of this tile's rows when ln_stats holds partial sums
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -502,6 +526,28 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 || MODE == 3 ? 3 
     }
   }
 
+  if (LNF == 2 && p.ln_parts > 0) {
+    // ln_stats holds the producer's partial (sum, sum of squares) per 64-column block of A's rows: [M][P][2].  The K loop ended on
+    // a barrier, the staging LDS is idle: this tile's rows arrive there by coalesced 16-byte loads (all in flight at once -- one L2
+    // round trip; a per-row loop of dependent loads cost 8-13 us per launch), then thread r reduces row r in slot order.
+    const int P2 = p.ln_parts * 2;
+    const int rows = min(BM, p.M - m0);
+    const int nvec = (rows * P2 + 3) >> 2;                 // m0 * P2 floats is a multiple of 256 floats: 16-byte aligned
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.ln_stats + (long)m0 * P2);
+    f32x4* stg = reinterpret_cast<f32x4*>(smem);
+    for (int i = tid; i < nvec; i += 256) stg[i] = src[i];
+    __syncthreads();
+    if (tid < BM) {
+      const float* pr = reinterpret_cast<const float*>(smem) + min(tid, rows - 1) * P2;
+      float sm = 0.0f, sq = 0.0f;
+      for (int i = 0; i < P2; i += 2) { sm += pr[i]; sq += pr[i + 1]; }
+      const float mean = sm / (float)p.K;
+      s_ln[2 * tid] = mean;
+      s_ln[2 * tid + 1] = rsqrtf(fmaxf(sq / (float)p.K - mean * mean, 0.0f) + p.ln_eps);
+    }
+    __syncthreads();                                       // the epilogue's transposition scratch reuses the same LDS
+  }
+
   // ---- epilogue ----
   // The accumulators hold D[n][m] (lane: column m = l31, rows n = 8g + 4hi + 0..3): stored directly, every lane
   // would write 8 bytes at a row stride -- 32 partial lines per store instruction.  Instead each wave transposes
@@ -616,12 +662,18 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 || MODE == 3 ? 3 
         r_mean = __shfl(ln_mean[tm], rr, 64);
         r_rstd = __shfl(ln_rstd[tm], rr, 64);
       } else if (LNF == 2) {
-        const float2 st2 = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)min(m, p.M - 1));
-        r_mean = st2.x;
-        r_rstd = st2.y;
+        if (p.ln_parts > 0) {
+          r_mean = s_ln[2 * (wm * 64 + tm * 32 + rr)];
+          r_rstd = s_ln[2 * (wm * 64 + tm * 32 + rr) + 1];
+        } else {
+          const float2 st2 = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)min(m, p.M - 1));
+          r_mean = st2.x;
+          r_rstd = st2.y;
+        }
       }
       float gcol[8];
       if (LNF) load_gcol(gcol);
+      float e_s = 0.0f, e_q = 0.0f;      // EMIT: this lane's share of the row's (sum, sum of squares)
       if (GEGLU) {
         const int n = n0 + wn * 32 + rc * 4;
         f32x4 hv = *reinterpret_cast<const f32x4*>(tile + rr * 64 + ((rc ^ (rr & 15)) * 4));
@@ -698,7 +750,17 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 || MODE == 3 ? 3 
 #pragma unroll
             for (int j = 0; j < 8; ++j) w[j] = from_f32<T>(o[j]);
             st8<T>(C + (long)m * p.ldc + n, w);
+            if (EMIT) row_sums8<T>(w, e_s, e_q);
           }
+        }
+        if (EMIT) {
+          // the 8 lanes rc = 0..7 of a row group hold this row's 64 columns of the wave (lanes past N hold zeros): sum them in a
+          // fixed tree, lane rc = 0 writes the slot.  Wave-uniform control flow: every lane takes part in the exchanges.
+          e_s = sum8_dpp(e_s);
+          e_q = sum8_dpp(e_q);
+          const int slot = (n0 + wn * 64) >> 6;
+          if (rc == 0 && m < p.M && n0 + wn * 64 < p.N)
+            *reinterpret_cast<float2*>(p.row_parts + ((long)m * ((p.N + 63) >> 6) + slot) * 2) = float2{e_s, e_q};
         }
       }
     }
@@ -771,6 +833,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
+// GemmArgs::row_parts for the routing targets whose epilogue does not emit it (big tile, split-K, exact-fit, row-stationary kernels):
+// one pass over the finished C -- 8 lanes per (row, 64-column block), 16 bytes per lane -- in the same layout and the same
+// summation tree as gemm2_kernel's EMIT epilogue (lane-local sum of 8 values, then sum8_dpp).
+template <typename T>
+__global__ __launch_bounds__(256) void row_parts_kernel(const T* __restrict__ C, long ldc, float* __restrict__ parts, int M, int N) {
+  using V8 = typename Vec<T>::v8;
+  const int P = (N + 63) >> 6;
+  const long g = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;       // (row, slot) group of 8 lanes
+  const int rc = threadIdx.x & 7;
+  const bool on = g < (long)M * P;
+  const int m = on ? (int)(g / P) : 0, slot = on ? (int)(g - (long)m * P) : 0;
+  const int n = slot * 64 + rc * 8;
+  float e_s = 0.0f, e_q = 0.0f;
+  if (on && n < N) row_sums8<T>(ld8<T>(C + (long)m * ldc + n), e_s, e_q);
+  e_s = sum8_dpp(e_s);
+  e_q = sum8_dpp(e_q);
+  if (on && rc == 0) *reinterpret_cast<float2*>(parts + ((long)m * P + slot) * 2) = float2{e_s, e_q};
+}
+
 // gemm_variant: 0 v1 (register-staged 128x128), 1 / 2 v2 (LDS-DMA 128x128) with 1 / 2 LDS stages, 3 auto among v2 only,
 // 4 / 5 force the 256x320 / 128x320 kernel of gemm3.hip wherever it is applicable, 6 auto over everything (default),
 // 7 / 8 force the PERSISTENT 256x320 / 128x320 kernel for GEMM / GEGLU (convs fall back to the auto rule)
@@ -790,8 +871,11 @@ static int g_last_splits = 1;    // hallo_get_option("last_gemm_splits"): split-
 static int g_gemm_rs = 2;        // hallo_set_option("gemm_rs", 0 | 1 | 2): row-stationary kernels for eligible K = 320 / 640 shapes (1: gemm_rs.hip only, 2: gemm_rs2.hip at K = 320)
 
 
+static int g_producer_stats = 1; // hallo_set_option("producer_stats", 0 | 1): read by the HOST side (hallo_amd/models): ask producers for row_parts / stats at all (A/B)
+static int g_row_parts = 1;      // hallo_set_option("row_parts", 0 | 1 | 2): 0 = GemmArgs::row_parts always by the extra pass (A/B of the EMIT epilogue); 2 = always the four-workgroups-per-CU form of the 1-stage EMIT kernel
+
 template <typename T>
-static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
+static int launch_gemm_impl(GemmArgs a, bool conv, bool geglu, int batch, void* ws, int64_t ws_bytes, hipStream_t st, bool* emitted) {
   const int nk = (a.K + BK - 1) / BK;
   a.splits = 1; a.nk_per_split = 0; a.slab = nullptr;
   int v = a.vec_ok ? g_gemm_variant : 0;
@@ -810,7 +894,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
   g_last_splits = 1;
   // ---- gemm4.hip: 128 x 160 tiles, one persistent workgroup per CU, stream-K tail (mid-size problems of the 32x32 ... 8x8 levels) ----
   if (g_gemm4 && v >= 3 && !conv && !geglu && !gelu && batch == 1 && a.vec_ok && !a.bias_per_row && a.act <= ACT_RELU && ws &&
-      (!lnf || (a.ln_stats != nullptr && !(reinterpret_cast<uintptr_t>(a.ln_colsum) & 15) && !(a.N & 7)))) {
+      a.ln_parts == 0 && (!lnf || (a.ln_stats != nullptr && !(reinterpret_cast<uintptr_t>(a.ln_colsum) & 15) && !(a.N & 7)))) {
     G4Sched gs;
     // the last 64 KB of the workspace hold the arrival counters (zero between launches): split-K slabs stay below them
     if (gemm4_plan(a, ws_bytes, &gs)) {
@@ -825,7 +909,8 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
       // hot) the exposed epilogues cost more than the quantisation they remove, and a K-split tail loses to the partly filled
       // round it replaces.  So: one round, K >= 2560.
       const bool one_round = (gs.dp == 1 && gs.R == 0) || (gs.dp == 0 && gs.parts == 1 && t4 >= 192);
-      const bool take = g_gemm4 == 2 || (one_round && nk >= g_gemm4_min_nk && a.N % 160 == 0);
+      const bool take = (g_gemm4 == 2 || (one_round && nk >= g_gemm4_min_nk && a.N % 160 == 0)) &&
+                        (gs.parts == 1 || a.ws_zeroed);      // a K-split tail counts arrivals in the workspace's counter tail: zero or no split
       if (take) {
         g_last_kernel = 600 + (lnf ? 2000 : 0);
         g_last_splits = gs.parts > 1 ? 1000 + gs.parts : 1;
@@ -940,6 +1025,8 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     }
   }
   dim3 grid(tiles, a.splits, batch), block(256);
+  // the 128 x 128 kernel's own row_parts epilogue: plain GEMM, one K pass, 16-bit output
+  const bool emit2 = g_row_parts && a.row_parts && v != 0 && a.splits == 1 && batch == 1 && !a.out_f32 && !conv && !geglu && !gelu && !lnf;
   g_last_splits = a.splits;
   g_last_kernel = (v == 0 ? 100 : 200) + 10 * (geglu ? 2 : (conv ? 1 : (gelu && v != 0 ? 3 : 0))) + (v == 0 ? 0 : v) +
                   1000 * (v != 0 && lnf ? (a.ln_stats ? 2 : 1) : 0);
@@ -955,6 +1042,12 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     else if (geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 1, 0>), grid, block, 0, st, a);
     else if (gelu) hipLaunchKernelGGL((gemm2_kernel<T, 3, 1, 0>), grid, block, 0, st, a);
     else if (conv) hipLaunchKernelGGL((gemm2_kernel<T, 1, 1, 0>), grid, block, 0, st, a);
+    else if (emit2) {
+      const int r4 = (tiles + 1023) / 1024, r3 = (tiles + 767) / 768;          // rounds at four / three workgroups per CU
+      if (r4 < r3 || g_row_parts == 2) hipLaunchKernelGGL((gemm2_kernel<T, 0, 1, 0, 1>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((gemm2_kernel<T, 0, 1, 0, 2>), grid, block, 0, st, a);
+      *emitted = true;
+    }
     else hipLaunchKernelGGL((gemm2_kernel<T, 0, 1, 0>), grid, block, 0, st, a);
   } else {
     if (lnf && a.ln_stats && geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 2, 2>), grid, block, 0, st, a);
@@ -964,6 +1057,7 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     else if (geglu) hipLaunchKernelGGL((gemm2_kernel<T, 2, 2, 0>), grid, block, 0, st, a);
     else if (gelu) hipLaunchKernelGGL((gemm2_kernel<T, 3, 2, 0>), grid, block, 0, st, a);
     else if (conv) hipLaunchKernelGGL((gemm2_kernel<T, 1, 2, 0>), grid, block, 0, st, a);
+    else if (emit2) { hipLaunchKernelGGL((gemm2_kernel<T, 0, 2, 0, 1>), grid, block, 0, st, a); *emitted = true; }
     else hipLaunchKernelGGL((gemm2_kernel<T, 0, 2, 0>), grid, block, 0, st, a);
   }
   HALLO_CHECK_LAUNCH();
@@ -972,6 +1066,19 @@ static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, i
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((n + 255) / 256)), block, 0, st, a);
     HALLO_CHECK_LAUNCH();
   }
+  return 0;
+}
+
+template <typename T>
+static int launch_gemm(GemmArgs a, bool conv, bool geglu, int batch, void* ws, int64_t ws_bytes, hipStream_t st) {
+  bool emitted = false;
+  const int rc = launch_gemm_impl<T>(a, conv, geglu, batch, ws, ws_bytes, st, &emitted);
+  if (rc != 0 || !a.row_parts || emitted) return rc;
+  // whatever kernel took the problem (incl. its split-K reduce pass) has written C on this stream: one pass over it
+  const long groups = (long)a.M * ((a.N + 63) >> 6);
+  hipLaunchKernelGGL((row_parts_kernel<T>), dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, st,
+                     reinterpret_cast<const T*>(a.C), a.ldc, a.row_parts, a.M, a.N);
+  HALLO_CHECK_LAUNCH();
   return 0;
 }
 
@@ -1011,6 +1118,11 @@ extern "C" int hallo_gemm(const hallo_gemm_desc* d, void* stream) {
   if (a.lead_cols & 7) return -22;
   a.ln_colsum = d->ln_colsum; a.ln_eps = d->ln_eps; a.ln_stats = d->ln_colsum ? d->ln_stats : nullptr;
   if (a.ln_colsum && (d->batch != 1 || d->out_f32 || d->bias_per_row)) return -22;
+  a.ln_parts = (a.ln_colsum && a.ln_stats && d->ln_parts > 0) ? d->ln_parts : 0;
+  if (d->ln_parts < 0 || (d->ln_parts > 0 && (!(d->ln_colsum && d->ln_stats) || (reinterpret_cast<uintptr_t>(d->ln_stats) & 15)))) return -22;
+  a.ws_zeroed = d->workspace_zeroed != 0;
+  a.row_parts = d->row_parts;
+  if (a.row_parts && (d->batch != 1 || d->out_f32 || d->geglu || (d->N & 7) || (reinterpret_cast<uintptr_t>(d->row_parts) & 15))) return -22;
   a.tiles_m = (d->M + BM - 1) / BM;
   a.tiles_n = d->geglu ? (d->N + 63) / 64 : (d->N + BN - 1) / BN;
   a.H = a.W = a.Cin = a.OH = a.OW = a.stride = a.pad_t = a.pad_l = a.upsample = 0;
@@ -1068,7 +1180,7 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
   a.residual = d->residual; a.ldr = d->ldr > 0 ? d->ldr : d->Cout; a.sR = 0;
   a.alpha = d->alpha; a.act = d->act; a.out_f32 = 0;
   a.lead_cols = 0; a.lead_alpha = 1.0f;
-  a.ln_colsum = nullptr; a.ln_eps = 0.0f; a.ln_stats = nullptr;
+  a.ln_colsum = nullptr; a.ln_eps = 0.0f; a.ln_stats = nullptr; a.ln_parts = 0; a.row_parts = nullptr; a.ws_zeroed = 0;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.OH = d->OH; a.OW = d->OW;
@@ -1104,6 +1216,8 @@ extern "C" int hallo_get_option(const char* name) {
   if (!strcmp(name, "gemm_rs_dbg")) return g_rs_dbg_value;
   if (!strcmp(name, "ff_fused")) return ff_fused_variant();
   if (!strcmp(name, "conv_fast")) return g_conv_fast;
+  if (!strcmp(name, "row_parts")) return g_row_parts;
+  if (!strcmp(name, "producer_stats")) return g_producer_stats;
   return hallo_get_option_attn(name);
 }
 
@@ -1113,6 +1227,8 @@ extern "C" int hallo_set_option(const char* name, int value) {
   if (!strcmp(name, "v3_min_tiles")) { if (value < 1) return -22; g_v3_min_tiles = value; return 0; }
   if (!strcmp(name, "conv_fast")) { if (value < 0 || value > 1) return -22; g_conv_fast = value; return 0; }
   if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }
+  if (!strcmp(name, "row_parts")) { if (value < 0 || value > 2) return -22; g_row_parts = value; return 0; }
+  if (!strcmp(name, "producer_stats")) { if (value < 0 || value > 1) return -22; g_producer_stats = value; return 0; }
   if (!strcmp(name, "gemm_rs")) { if (value < 0 || value > 2) return -22; g_gemm_rs = value; return 0; }
   if (!strcmp(name, "gemm4")) { if (value < 0 || value > 2) return -22; g_gemm4 = value; return 0; }
   if (!strcmp(name, "gemm4_min_nk")) { if (value < 4) return -22; g_gemm4_min_nk = value; return 0; }

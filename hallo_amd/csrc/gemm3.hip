@@ -62,6 +62,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   // persistent mode keeps slot 1 clear of the 64 KB epilogue scratch at the start of the array
   constexpr int SLOT_STRIDE = (PERSIST && SLOT < 32768) ? 32768 : SLOT;
   __shared__ __attribute__((aligned(16))) T smem[SLOT_STRIDE + SLOT];
+  // GemmArgs::ln_parts > 0 (round 5): ln_stats holds the producer's partial (sum, sum of squares) per 64-column block of A's rows;
+  // (mean, rstd) of this tile's rows are reduced here in slot order.  Two buffers by tile parity: in persistent mode a fast wave
+  // is in the next tile's prologue while a slow one still reads this tile's values in its epilogue (the K loop's barriers order
+  // everything two tiles apart).
+  __shared__ float s_ln[CONV ? 2 : 2 * 2 * BM];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -279,6 +284,26 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   for (int kt = kt_begin; kt + 1 < kt_end; ++kt) kstep(std::true_type{}, kt);
   if (kt_begin < kt_end) kstep(std::false_type{}, kt_end - 1);
   __builtin_amdgcn_s_barrier();   // every wave is done with the staging LDS: the epilogue reuses it
+  if (!CONV && p.ln_parts > 0 && p.ln_colsum != nullptr) {
+    // the producer's partial (sum, sum of squares) per 64-column block of this tile's A rows -> (mean, rstd) per row: coalesced
+    // 16-byte loads into slot 0 (idle; the persistent prefetch below goes to slot 1), then thread r reduces row r in slot order
+    const int P2 = p.ln_parts * 2;
+    const int rows = min(BM, p.M - m0);
+    const int nvec = (rows * P2 + 3) >> 2;
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.ln_stats + (long)m0 * P2);
+    f32x4* stg = reinterpret_cast<f32x4*>(smem);
+    for (int i = tid; i < nvec; i += 512) stg[i] = src[i];
+    __syncthreads();
+    if (tid < BM) {
+      const float* pr = reinterpret_cast<const float*>(smem) + min(tid, rows - 1) * P2;
+      float sm = 0.0f, sq = 0.0f;
+      for (int i = 0; i < P2; i += 2) { sm += pr[i]; sq += pr[i + 1]; }
+      const float mean = sm / (float)p.K;
+      s_ln[(it & 1) * 2 * BM + 2 * tid] = mean;
+      s_ln[(it & 1) * 2 * BM + 2 * tid + 1] = rsqrtf(fmaxf(sq / (float)p.K - mean * mean, 0.0f) + p.ln_eps);
+    }
+    __syncthreads();
+  }
   if (PERSIST) {
     // next tile of this workgroup: loader state + DMA of its K step 0 into slot 1 (the epilogue scratch is in slot 0)
     const int nvt = vt + (int)gridDim.x;
@@ -356,7 +381,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
           if (lane_on && m < p.M && n < p.N) {
             float vs = GELU_U_INV, gs = GELU_U_SCALE, vc = 0.0f, gc = 0.0f;      // out = scale * acc + shift * G[n] + bias'
             if (lnf) {
-              const float mean = p.ln_stats[2 * (long)m], rstd = p.ln_stats[2 * (long)m + 1];
+              const int lr = (it & 1) * 2 * BM + 2 * (wm * 32 * TM + tm * 32 + rr);
+              const float mean = p.ln_parts > 0 ? s_ln[lr] : p.ln_stats[2 * (long)m];
+              const float rstd = p.ln_parts > 0 ? s_ln[lr + 1] : p.ln_stats[2 * (long)m + 1];
               vs *= rstd; gs *= rstd; vc = -mean * vs; gc = -mean * gs;
             }
             V4 o;
@@ -418,8 +445,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
         float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         float t8[8];
         const float br = (bias && p.bias_per_row) ? to_f32(bias[m]) : 0.0f;
-        if (lnf) {       // fused LayerNorm: rstd * (acc - mean * G[n]) with the statistics of hallo_row_stats
-          const float mean = p.ln_stats[2 * (long)m], rstd = p.ln_stats[2 * (long)m + 1];
+        if (lnf) {       // fused LayerNorm: rstd * (acc - mean * G[n]) with the statistics of hallo_row_stats (or the producer's partial sums)
+          const int lr = (it & 1) * 2 * BM + 2 * (wm * 32 * TM + tm * 32 + rr);
+          const float mean = p.ln_parts > 0 ? s_ln[lr] : p.ln_stats[2 * (long)m];
+          const float rstd = p.ln_parts > 0 ? s_ln[lr + 1] : p.ln_stats[2 * (long)m + 1];
           const float c1 = -mean * rstd;
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(rstd, o[j], c1 * gcol[j]);

@@ -24,6 +24,9 @@ struct GemmArgs {
   const float* ln_stats;    // optional [M][2] fp32 (mean, rstd) from hallo_row_stats: then the K loop does no statistics work
   float ln_eps;             // the kernel accumulates per-row sum / sum of squares over K next to the MFMAs and applies
                             // out = rstd_m * (acc - mean_m * ln_colsum[n]) + bias.  ln_colsum[n] = sum_k W[n,k] (fp32, [N] / GEGLU [2N])
+  int ln_parts;             // > 0: ln_stats is [M][ln_parts][2] partial (sum, sum of squares) -- reduced to mean / rstd per row in the prologue
+  int ws_zeroed;            // the workspace's counter tail is known to be zero (hallo_gemm_desc.workspace_zeroed): gemm4.hip may split a tile's K loop
+  float* row_parts;         // optional out: [M][ceil(N / 64)][2] (sum, sum of squares) of the rounded output rows per 64-column block
   int act;
   int out_f32;
   int tiles_n, tiles_m;

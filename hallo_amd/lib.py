@@ -44,6 +44,9 @@ class GemmDesc(C.Structure):
         ("ln_colsum", C.c_void_p),
         ("ln_eps", C.c_float),
         ("ln_stats", C.c_void_p),
+        ("row_parts", C.c_void_p),
+        ("ln_parts", C.c_int),
+        ("workspace_zeroed", C.c_int),
     ]
 
 
@@ -127,6 +130,8 @@ SYMBOLS = {
     "hallo_gemm4_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
     "hallo_face_xattn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
+    "hallo_face_xattn_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "hallo_ff320_pack_bytes": (C.c_int64, []),
     "hallo_ff320": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                               C.c_int, C.c_float, C.c_int, C.c_void_p]),

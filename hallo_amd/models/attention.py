@@ -137,7 +137,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         self.attn1.fold_norm(self.norm1)
         self.ff.fold_norm(self.norm3)
 
-    def run(self, x, enc, bank, video_length, do_cfg, cache=NO_CACHE, bank_layout=None):
+    def run(self, x, enc, bank, video_length, do_cfg, cache=NO_CACHE, bank_layout=None, stats=None):
         """x [n = b*f, L, C]; enc [b, T, Cx] face tokens; bank [b*s, L, C] (s = 1 reference + motion frames,
         fp16-rounded: ReferenceAttentionControl.update casts to fp16 whatever the run dtype, :404,452).
         bank_layout = (bank batches bb, this call's first batch, its first global frame row row0): the call evaluates a SLICE
@@ -147,7 +147,7 @@ class TemporalBasicTransformerBlock(nn.Module):
         b = n // video_length
         bb, _, row0 = bank_layout if bank_layout is not None else (b, 0, 0)
         a1 = self.attn1
-        _, q, k, v = a1.qkv_ln(x)
+        _, q, k, v = a1.qkv_ln(x, stats=stats)       # stats: norm1's statistics from proj_in's epilogue
         if do_cfg == SKIP_BANK:
             # the uncond half of a CFG evaluation run on its own (FaceAnimatePipeline(cfg_split=True)): its rows attend to
             # themselves only (mutual_self_attention.py:264-284), the bank segment does not exist for this call
@@ -183,6 +183,11 @@ class TemporalBasicTransformerBlock(nn.Module):
                 return ops.face_xattn_constants(a2.to_q.weight, k0, v0, a2.to_out[0].weight, self.norm2.weight,
                                                 self.norm2.bias, a2.heads, x.dtype)
             sg, g, bb, owp = cache.get(self, "face_fused", face_consts)
+            if self.ff.takes_stats(n * L):
+                # the kernel holds whole output rows: norm3's statistics leave with them
+                x, st3 = ops.face_xattn(x.view(n * L, Cd), sg, g, bb, owp, a2.to_out[0].bias, video_length * L, self.norm2.eps,
+                                        stats_eps=self.norm3.eps)
+                return self.ff.run_ln(x.view(n, L, Cd), stats=st3)
             x = ops.face_xattn(x.view(n * L, Cd), sg, g, bb, owp, a2.to_out[0].bias, video_length * L,
                                self.norm2.eps).view(n, L, Cd)
         else:
@@ -237,12 +242,17 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
         self.ff.fold_norm(self.norm3)
         self.w_q3_ln, self.g_q3_ln, self.b_q3_ln = ops.fold_layernorm(self.norm2.weight, self.norm2.bias, self.w_q3)
 
-    def run(self, x, audio, masks, motion_scale, cache=NO_CACHE):
-        """x [n, L, D]; audio [n, 32, Ca]; masks = (full, face, lip), each fp32 [n, L] for this block's depth."""
+    def run(self, x, audio, masks, motion_scale, cache=NO_CACHE, stats=None):
+        """x [n, L, D]; audio [n, 32, Ca]; masks = (full, face, lip), each fp32 [n, L] for this block's depth.
+        stats: norm1's statistics of x from proj_in's epilogue, if any."""
         n, L, D = x.shape
-        _, q, k, v = self.attn1.qkv_ln(x)
+        _, q, k, v = self.attn1.qkv_ln(x, stats=stats)
         a = ops.attention(q, k, v, self.attn1.heads, q_prescaled=True)
-        x = self.attn1.out(a, residual=x)
+        st2 = None
+        if ops.wants_stats(n * L, 3 * D, D):
+            x, st2 = self.attn1.out(a, residual=x, row_parts=True)     # norm2's statistics from to_out's epilogue
+        else:
+            x = self.attn1.out(a, residual=x)
 
         def audio_kv():
             T = audio.shape[1]
@@ -266,11 +276,14 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
 
         x2 = x.view(n * L, D)
         q3 = ops.gemm(x2, self.w_q3_ln, self.b_q3_ln, alpha=ops.q_scale(self.attn2_0.dim_head), ln_colsum=self.g_q3_ln,
-                      ln_eps=self.norm2.eps, ln_stats=ops.ln_stats(x2, 3 * D, self.norm2.eps)).view(n, L, 3 * D)
+                      ln_eps=self.norm2.eps, ln_stats=ops.ln_stats(x2, 3 * D, self.norm2.eps, given=st2)).view(n, L, 3 * D)
         # three branches x heads as one attention launch; output rows pre-scaled by motion_scale[i] * mask_i
         # (attention.py:853-903) and written straight into the fused GEMM's A operand
         ops.attention(q3, kv3[:, :, :3 * D], kv3[:, :, 3 * D:], 3 * self.attn2_0.heads,
                       out=A.view(n, L, 3 * D + 8)[:, :, :3 * D], rowscale=msmask, rowscale_head_div=self.attn2_0.heads,
                       q_prescaled=True)
+        if self.ff.takes_stats(n * L):
+            x, st3 = ops.gemm(A, self.w_fused, bias_c, residual=x.view(n * L, D), row_parts=True)     # norm3's statistics
+            return self.ff.run_ln(x.view(n, L, D), stats=st3)
         x = ops.gemm(A, self.w_fused, bias_c, residual=x.view(n * L, D)).view(n, L, D)
         return self.ff.run_ln(x)

@@ -254,8 +254,9 @@ class Attention(nn.Module):
             self._o8, self._o8s = ops.quant_rows_fp8(self.to_out[0].weight)
         self.fp8 = bool(enabled) and not self.is_cross
 
-    def qkv_ln(self, x, bias2=None, bias2_rows_per_group=0):
-        """x [N, L, C] UN-normalised -> fused [N, L, 3*inner] of LN(x) (+ bias2: PE @ W^T rows), q pre-scaled."""
+    def qkv_ln(self, x, bias2=None, bias2_rows_per_group=0, stats=None):
+        """x [N, L, C] UN-normalised -> fused [N, L, 3*inner] of LN(x) (+ bias2: PE @ W^T rows), q pre-scaled.
+        stats: LayerNorm statistics of x's rows from the kernel that produced x (ops.RowParts / [rows, 2]), if any."""
         N, L, Cd = x.shape
         x2 = x.view(N * L, Cd)
         if self.fp8 and bias2 is None:
@@ -268,18 +269,23 @@ class Attention(nn.Module):
         y = ops.gemm(x2, self._ln_w, self._ln_b, lead_cols=self.inner, lead_alpha=ops.q_scale(self.dim_head),
                      ln_colsum=self._ln_g, ln_eps=self._ln_eps,
                      ln_stats=ops.ln_stats(x2, 3 * self.inner, self._ln_eps, bias2_rows_per_group=bias2_rows_per_group if bias2 is not None else 0,
-                                           lead_cols=self.inner), bias2=bias2,
+                                           lead_cols=self.inner, given=stats), bias2=bias2,
                      bias2_rows_per_group=bias2_rows_per_group).view(N, L, 3 * self.inner)
         i = self.inner
         return y, y[:, :, :i], y[:, :, i:2 * i], y[:, :, 2 * i:]
 
     def out(self, a, residual=None, **epi):
-        """to_out.0 (+ residual) on a [N, L, inner]."""
+        """to_out.0 (+ residual) on a [N, L, inner].  row_parts=True: returns (y, ops.RowParts of y's rows or None)."""
         N, L, _ = a.shape
         r = residual.view(N * L, -1) if residual is not None else None
+        want = epi.pop("row_parts", False)
         if self.fp8 and not epi:
             aq, sa = ops.quant_rows_fp8(a.view(N * L, self.inner))
-            return ops.gemm_fp8(aq, sa, self._o8, self._o8s, a.dtype, self.to_out[0].bias, residual=r).view(N, L, -1)
+            y = ops.gemm_fp8(aq, sa, self._o8, self._o8s, a.dtype, self.to_out[0].bias, residual=r).view(N, L, -1)
+            return (y, None) if want else y
+        if want:
+            y, parts = self.to_out[0].run(a.view(N * L, self.inner), residual=r, row_parts=True, **epi)
+            return y.view(N, L, -1), parts
         y = self.to_out[0].run(a.view(N * L, self.inner), residual=r, **epi)
         return y.view(N, L, -1)
 
@@ -317,9 +323,16 @@ class FeedForward(nn.Module):
         self._ff_pack = None
         self._ff_pack_ok = g.weight.shape[1] == ops.FF320_C and g.weight.shape[0] == 2 * ops.FF320_INNER and g.weight.is_cuda
 
-    def run_ln(self, x):
+    def takes_stats(self, rows):
+        """Does run_ln on `rows` rows read LayerNorm statistics of its input (False: the fused 320-wide kernel normalises the
+        rows it holds)?  What a producer asks before it spends epilogue work on them."""
+        if self._ff_pack_ok and ops.ff320_enabled(rows):
+            return False
+        return ops.wants_stats(rows, self._ln_w.shape[0] // 2, self._ln_w.shape[1], geglu=True)
+
+    def run_ln(self, x, stats=None):
         """x [N, L, C] UN-normalised -> ff(LayerNorm(x)) + x: one fused kernel for 320-wide blocks with enough rows, else the
-        norm fused into the GEGLU GEMM and the residual into net[2]'s."""
+        norm fused into the GEGLU GEMM and the residual into net[2]'s.  stats: the rows' statistics from x's producer, if any."""
         N, L, Cd = x.shape
         x2 = x.view(N * L, Cd)
         if self._ff_pack_ok and ops.ff320_enabled(N * L):
@@ -328,7 +341,7 @@ class FeedForward(nn.Module):
                 ops.publish_constant()          # shared by every pipeline / stream that runs this module
             return ops.ff320(x2, self._ff_pack, self.net[2].bias, eps=self._ln_eps).view(N, L, Cd)
         h = ops.gemm(x2, self._ln_w, self._ln_b, geglu=True, ln_colsum=self._ln_g, ln_eps=self._ln_eps,
-                     ln_stats=ops.ln_stats(x2, self._ln_w.shape[0] // 2, self._ln_eps, geglu=True))
+                     ln_stats=ops.ln_stats(x2, self._ln_w.shape[0] // 2, self._ln_eps, geglu=True, given=stats))
         y = self.net[2].run(h, residual=x.view(N * L, Cd))
         return y.view(N, L, Cd)
 

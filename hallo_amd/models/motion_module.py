@@ -69,8 +69,8 @@ class TemporalTransformerBlock(nn.Module):
             ops.publish_constant()              # shared by every pipeline / stream that runs this module
         return self._pe_bias[key]
 
-    def run(self, h, batch, frames, drop=0):
-        """h [batch*frames, L, C].  drop > 0 (batch 1 only): the caller discards the first `drop` frames of the result (the
+    def run(self, h, batch, frames, drop=0, stats=None):
+        """h [batch*frames, L, C]; stats: the first norm's statistics of h from proj_in's epilogue, if any.  drop > 0 (batch 1 only): the caller discards the first `drop` frames of the result (the
         motion frames put in front of the clip, unet_3d_blocks.py:696-748).  Everything behind the LAST temporal attention is
         row-wise (to_out, the feed-forward, proj_out), so those rows are not computed at all: the frames still take part as
         keys / values, the kept rows are bit-for-bit what the full computation gives, and [frames - drop, L, C] is returned."""
@@ -81,13 +81,19 @@ class TemporalTransformerBlock(nn.Module):
             # row r = (b*frames + f)*L + pixel -> bias2 row r / L
             h2 = h.view(n * L, Cd)
             qkv = ops.gemm(h2, wf, bf, ln_colsum=gcs, ln_eps=norm.eps,
-                           ln_stats=ops.ln_stats(h2, 3 * Cd, norm.eps, bias2_rows_per_group=L),
+                           ln_stats=ops.ln_stats(h2, 3 * Cd, norm.eps, bias2_rows_per_group=L, given=stats),
                            bias2=self._pe_rows(i, attn, batch, frames), bias2_rows_per_group=L).view(n, L, 3 * Cd)
             a = ops.temporal_attention(qkv, batch, frames, L, Cd, attn.heads)
             if drop and i == last:
                 a, h = a[drop:], h[drop:]
-            h = attn.out(a, residual=h)
-        return self.ff.run_ln(h)
+            # the next consumer of h is a LayerNorm-fused GEMM (the next attention's q|k|v, or the feed-forward): its statistics
+            # leave with to_out's epilogue
+            k = h.shape[0]
+            if (ops.wants_stats(k * L, 3 * Cd, Cd, bias2_rows_per_group=L) if i < last else self.ff.takes_stats(k * L)):
+                h, stats = attn.out(a, residual=h, row_parts=True)
+            else:
+                h, stats = attn.out(a, residual=h), None
+        return self.ff.run_ln(h, stats=stats)
 
 
 class TemporalTransformer3DModel(nn.Module):
@@ -105,10 +111,15 @@ class TemporalTransformer3DModel(nn.Module):
         n, L, Cd = x.shape
         assert drop == 0 or batch == 1
         h = self.norm.run(x)
-        h = self.proj_in.run(h.view(n * L, Cd)).view(n, L, self.inner)
+        st = None
+        if ops.wants_stats(n * L, 3 * self.inner, self.inner, bias2_rows_per_group=L):
+            h, st = self.proj_in.run(h.view(n * L, Cd), row_parts=True)
+        else:
+            h = self.proj_in.run(h.view(n * L, Cd))
+        h = h.view(n, L, self.inner)
         nb = len(self.transformer_blocks)
         for i, blk in enumerate(self.transformer_blocks):
-            h = blk.run(h, batch, frames, drop if i == nb - 1 else 0)
+            h = blk.run(h, batch, frames, drop if i == nb - 1 else 0, stats=st if i == 0 else None)
         k = h.shape[0]                                       # n, or n - drop
         return self.proj_out.run(h.view(k * L, self.inner), residual=x[n - k:].view(k * L, Cd)).view(k, L, Cd)
 

@@ -8,6 +8,7 @@ epilogue carries the residual add.
 """
 from torch import nn
 
+from .. import ops
 from .attention import NO_CACHE, AudioTemporalBasicTransformerBlock, TemporalBasicTransformerBlock
 from .layers import Conv1x1, GroupNorm
 
@@ -28,16 +29,23 @@ class Transformer3DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([blk])
         self.proj_out = Conv1x1(inner, in_channels)
 
+    def _proj_in(self, h2d):
+        # the consumer of proj_in's output: the block's LayerNorm-fused q|k|v projection (K = inner, 3 inner columns, q columns scaled)
+        if ops.wants_stats(h2d.shape[0], 3 * self.inner, self.inner, lead_cols=self.inner):
+            return self.proj_in.run(h2d, row_parts=True)
+        return self.proj_in.run(h2d), None
+
     def run_spatial(self, x, enc, bank, video_length, do_cfg, cache=NO_CACHE, bank_layout=None):
         n, L, Cd = x.shape
         h = self.norm.run(x)
-        h = self.proj_in.run(h.view(n * L, Cd)).view(n, L, self.inner)
-        h = self.transformer_blocks[0].run(h, enc, bank, video_length, do_cfg, cache, bank_layout)
+        # proj_in's epilogue delivers the statistics of norm1 (round 5: no hallo_row_stats pass over its output)
+        h, st = self._proj_in(h.view(n * L, Cd))
+        h = self.transformer_blocks[0].run(h.view(n, L, self.inner), enc, bank, video_length, do_cfg, cache, bank_layout, stats=st)
         return self.proj_out.run(h.view(n * L, self.inner), residual=x.view(n * L, Cd)).view(n, L, Cd)
 
     def run_audio(self, x, audio, masks, motion_scale, cache=NO_CACHE, out=None):
         n, L, Cd = x.shape
         h = self.norm.run(x)
-        h = self.proj_in.run(h.view(n * L, Cd)).view(n, L, self.inner)
-        h = self.transformer_blocks[0].run(h, audio, masks, motion_scale, cache)
+        h, st = self._proj_in(h.view(n * L, Cd))
+        h = self.transformer_blocks[0].run(h.view(n, L, self.inner), audio, masks, motion_scale, cache, stats=st)
         return self.proj_out.run(h.view(n * L, self.inner), residual=x.view(n * L, Cd), out=out).view(n, L, Cd)

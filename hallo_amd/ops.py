@@ -59,7 +59,8 @@ def option_epoch():
 
 
 ROUTING_OPTION_NAMES = ("gemm_variant", "split_k", "split_k_max", "v3_min_tiles", "gemm4", "gemm4_min_nk", "gemm_stage_min_tiles",
-                        "gemm_rs", "ff_fused", "conv_fast", "attn40", "temporal_mfma", "attn_order", "tok_attn", "gn_fused", "xattn_tiled")
+                        "gemm_rs", "ff_fused", "conv_fast", "attn40", "temporal_mfma", "attn_order", "tok_attn", "gn_fused", "xattn_tiled",
+                        "row_parts", "producer_stats")
 
 
 def options_fingerprint():
@@ -127,6 +128,7 @@ def get_option(name):
 
 SPLITK_WS_BYTES = 128 << 20
 GN_WS_FLOATS = 1 << 20
+WS_ZEROED = 1       # hallo_gemm_desc.workspace_zeroed as gemm() passes it: Scratch zeroes the counter tail once (tests set 0 to check the refusal)
 
 
 class Scratch:
@@ -198,12 +200,24 @@ def publish_constant():
     torch.cuda.current_stream().synchronize()
 
 
+class RowParts:
+    """LayerNorm statistics of a tensor's rows, delivered by the kernel that PRODUCED the tensor (hallo_gemm_desc.row_parts):
+    fp32 [rows, parts, 2] = (sum, sum of squares) of the rounded values of each 64-column block.  A LayerNorm-fused consumer
+    (gemm(..., ln_stats=RowParts)) reduces them to mean / rstd in its prologue; no pass over the tensor (hallo_row_stats)."""
+    __slots__ = ("sums", "parts", "rows", "cols")
+
+    def __init__(self, sums, parts, rows, cols):
+        self.sums, self.parts, self.rows, self.cols = sums, parts, rows, cols
+
+
 def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, act=ACT_NONE, geglu=False,
          bias2=None, bias2_rows_per_group=0, out_f32=False, bias_per_row=False, lead_cols=0, lead_alpha=1.0,
-         ln_colsum=None, ln_eps=1e-5, ln_stats=None):
+         ln_colsum=None, ln_eps=1e-5, ln_stats=None, row_parts=False):
     """out[M,N] = act(alpha * rowscale * (a[M,K] @ w[N,K]^T + bias) + residual).
 
-    a may be a 2-D view with arbitrary row stride (last dim contiguous).  geglu: w is [2N,K]."""
+    a may be a 2-D view with arbitrary row stride (last dim contiguous).  geglu: w is [2N,K].
+    row_parts=True: returns (out, RowParts) -- the output rows' LayerNorm partial sums from the epilogue.
+    ln_stats: fp32 [M, 2] (mean, rstd) from row_stats / face_xattn, or a RowParts of `a` from its producer."""
     _chk_dev(a, w)
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1
     M, K = a.shape
@@ -237,16 +251,29 @@ def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, 
         # fused LayerNorm: `a` is the un-normalised input, w / bias / ln_colsum come from fold_layernorm()
         assert ln_colsum.dtype == torch.float32 and ln_colsum.is_contiguous() and ln_colsum.numel() == w.shape[0]
         d.ln_colsum, d.ln_eps = ln_colsum.data_ptr(), float(ln_eps)
-        if ln_stats is not None:
-            assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.numel() == 2 * M
-        d.ln_stats = ln_stats.data_ptr() if ln_stats is not None else None
+        d.ln_parts = 0
+        if isinstance(ln_stats, RowParts):
+            assert ln_stats.rows == M and ln_stats.cols == K, (ln_stats.rows, ln_stats.cols, M, K)
+            d.ln_stats, d.ln_parts = ln_stats.sums.data_ptr(), ln_stats.parts
+        else:
+            if ln_stats is not None:
+                assert ln_stats.dtype == torch.float32 and ln_stats.is_contiguous() and ln_stats.numel() == 2 * M
+            d.ln_stats = ln_stats.data_ptr() if ln_stats is not None else None
     else:
-        d.ln_colsum, d.ln_eps, d.ln_stats = None, 0.0, None
+        d.ln_colsum, d.ln_eps, d.ln_stats, d.ln_parts = None, 0.0, None, 0
     d.dtype = dtype_code(a.dtype)
+    parts = None
+    if row_parts:
+        assert not geglu and not out_f32 and N % 8 == 0
+        P = (N + 63) // 64
+        parts = RowParts(torch.empty((M, P, 2), device=a.device, dtype=torch.float32), P, M, N)
+        d.row_parts = parts.sums.data_ptr()
+    else:
+        d.row_parts = None
     ws = _workspace(a.device)
-    d.workspace, d.workspace_bytes = ws.data_ptr(), SPLITK_WS_BYTES
+    d.workspace, d.workspace_bytes, d.workspace_zeroed = ws.data_ptr(), SPLITK_WS_BYTES, WS_ZEROED
     _l.check(_l.load().hallo_gemm(C.byref(d), _stream()), "hallo_gemm")
-    return out
+    return (out, parts) if row_parts else out
 
 
 def gemm_batched(a, w, out, *, out_f32=False, alpha=1.0, bias=None, bias_per_row=False, bias_stride=None, act=ACT_NONE,
@@ -273,9 +300,9 @@ def gemm_batched(a, w, out, *, out_f32=False, alpha=1.0, bias=None, bias_per_row
         d.residual, d.ldr, d.stride_r = residual.data_ptr(), residual.stride(1), residual.stride(0)
     d.alpha, d.act, d.geglu, d.out_f32 = float(alpha), act, 0, 1 if out_f32 else 0
     d.lead_cols, d.lead_alpha = 0, 1.0
-    d.ln_colsum, d.ln_eps, d.ln_stats = None, 0.0, None
+    d.ln_colsum, d.ln_eps, d.ln_stats, d.ln_parts, d.row_parts = None, 0.0, None, 0, None
     d.dtype = dtype_code(a.dtype)
-    d.workspace, d.workspace_bytes = None, 0
+    d.workspace, d.workspace_bytes, d.workspace_zeroed = None, 0, 0
     _l.check(_l.load().hallo_gemm(C.byref(d), _stream()), "hallo_gemm(batched)")
     return out
 
@@ -485,9 +512,11 @@ def frames_to_uint8(x, out=None):
     return out
 
 
-def face_xattn(x, sg, g, b, owp, bo, rows_per_batch, eps, out=None):
+def face_xattn(x, sg, g, b, owp, bo, rows_per_batch, eps, out=None, stats_eps=None):
     """y = x + to_out(SDPA(to_q(LN(x)), K, V)) over 32 (head, token) pairs with the projections / LayerNorm affine folded
-    into per-clip constants (see include/hallo_amd.h: hallo_face_xattn).  x [rows, C]; out may be x."""
+    into per-clip constants (see include/hallo_amd.h: hallo_face_xattn).  x [rows, C]; out may be x.
+    stats_eps: returns (y, stats) with stats fp32 [rows, 2] = (mean, rstd) of y's rows for a LayerNorm with that eps, from the
+    kernel's own epilogue (hallo_face_xattn_stats)."""
     _chk_dev(x, sg, owp)
     rows, Cd = x.shape
     assert x.is_contiguous() and sg.shape[-2:] == (32, Cd) and owp.shape[-2:] == (Cd, 32)
@@ -495,6 +524,12 @@ def face_xattn(x, sg, g, b, owp, bo, rows_per_batch, eps, out=None):
     assert sg.is_contiguous() and owp.is_contiguous() and sg.dtype == x.dtype and owp.dtype == x.dtype
     if out is None:
         out = torch.empty_like(x)
+    if stats_eps is not None:
+        st = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+        _l.check(_l.load().hallo_face_xattn_stats(_p(x), _p(out), _p(sg), _p(g), _p(b), _p(owp), _p(bo), rows, Cd,
+                                                   int(rows_per_batch), float(eps), _p(st), float(stats_eps), dtype_code(x.dtype),
+                                                   _stream()), "hallo_face_xattn_stats")
+        return out, st
     _l.check(_l.load().hallo_face_xattn(_p(x), _p(out), _p(sg), _p(g), _p(b), _p(owp), _p(bo), rows, Cd,
                                          int(rows_per_batch), float(eps), dtype_code(x.dtype), _stream()),
              "hallo_face_xattn")
@@ -650,14 +685,29 @@ def gemm_fp8(aq, a_scale, wq, w_scale, out_dtype, bias=None, *, residual=None, a
     return out
 
 
-def ln_stats(x2d, n_out, eps=1e-5, *, geglu=False, bias2_rows_per_group=0, lead_cols=0):
+def ln_stats(x2d, n_out, eps=1e-5, *, geglu=False, bias2_rows_per_group=0, lead_cols=0, given=None):
     """`ln_stats` argument for a LayerNorm-fused gemm(x2d, w[n_out(, x2), K], ...): None when the library's row-stationary
     kernel will take the problem and derive mean / rstd from the A rows it keeps in registers (hallo_gemm_fuses_row_stats),
-    else the statistics from hallo_row_stats."""
+    else `given` -- what the producer of x2d delivered (a RowParts from gemm(row_parts=True), or [M, 2] from face_xattn) --
+    else the statistics from hallo_row_stats (one pass over x2d)."""
     M, K = x2d.shape
     if x2d.is_contiguous() and _l.load().hallo_gemm_fuses_row_stats(M, n_out, K, 1 if geglu else 0, bias2_rows_per_group, lead_cols):
         return None
+    if given is not None:
+        return given
     return row_stats(x2d, eps)
+
+
+def producer_stats():
+    """hallo_set_option("producer_stats", 0) (A/B) turns the producer-side LayerNorm statistics off altogether."""
+    return get_option("producer_stats") > 0
+
+
+def wants_stats(M, n_out, K, *, geglu=False, bias2_rows_per_group=0, lead_cols=0):
+    """Should the producer of an [M, K] tensor emit LayerNorm statistics for the LayerNorm-fused gemm(x, w[n_out(, x2), K]) that
+    consumes it?  No when the mechanism is off, or when that consumer runs on the row-stationary kernel (it takes the
+    statistics from the A rows it keeps in registers: hallo_gemm_fuses_row_stats)."""
+    return producer_stats() and not _l.load().hallo_gemm_fuses_row_stats(M, n_out, K, 1 if geglu else 0, bias2_rows_per_group, lead_cols)
 
 
 _w2v_ws = {}

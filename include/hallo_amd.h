@@ -101,6 +101,20 @@ typedef struct hallo_gemm_desc {
   const float* ln_colsum;
   float ln_eps;
   const float* ln_stats;     /* optional [M][2] fp32 (mean, rstd) from hallo_row_stats; NULL: computed inside the K loop */
+  /* ABI v7 (round 5): LayerNorm statistics from the PRODUCER of a tensor instead of a pass over it (hallo_row_stats).
+   * row_parts (out, optional): fp32 [M][ceil(N / 64)][2] -- (sum, sum of squares) of every output row over each 64-column block,
+   *   taken from the ROUNDED values written to C (what a later nn.LayerNorm over C's rows would read).  The 128 x 128 kernel
+   *   emits them from its epilogue registers; every other routing target fills the same layout with one extra pass over C
+   *   (the cost of hallo_row_stats), so the contract holds for any problem.  batch = 1, dtype output, no geglu.
+   * ln_parts (in, with ln_colsum): when > 0, ln_stats is such a buffer -- [M][ln_parts][2] partial sums over the K columns of A
+   *   (ln_parts = ceil(K / 64) for a hallo_gemm producer) -- and the kernel reduces them to mean / rstd (eps = ln_eps) for its
+   *   rows in its prologue, in slot order.  0: ln_stats is [M][2] (mean, rstd) as before (hallo_row_stats, hallo_face_xattn_stats). */
+  float* row_parts;
+  int ln_parts;
+  /* ABI v7: 1 = the caller guarantees that the last 64 KB of `workspace` were zero before the first launch that used this workspace
+   * and have been written by nothing but hallo_gemm since (the stream-K kernel's arrival counters; every launch restores them).
+   * 0 (what a v6-style caller that hands over uninitialised scratch gets): K-split tails are not used -- whole tiles only. */
+  int workspace_zeroed;
 } hallo_gemm_desc;
 int hallo_gemm(const hallo_gemm_desc* d, void* stream);
 
@@ -327,6 +341,12 @@ int hallo_ff320(const void* x, int64_t ldx, const void* res, int64_t ldr, void* 
  */
 int hallo_face_xattn(const void* x, void* y, const void* sg, const float* g, const float* b, const void* owp,
                      const void* bo, int64_t rows, int C, int64_t rows_per_batch, float eps, int dtype, void* stream);
+/* ABI v7: the same, and stats_out (optional) [rows][2] fp32 = (mean, rstd) over C of every OUTPUT row as written (rounded), with
+ * LayerNorm eps = stats_eps: what hallo_row_stats(y) would give, from the kernel's own epilogue -- the statistics of norm3 in front
+ * of the block's feed-forward (hallo/models/attention.py:586-601) without a pass over y.  (The kernel already holds whole rows.) */
+int hallo_face_xattn_stats(const void* x, void* y, const void* sg, const float* g, const float* b, const void* owp,
+                           const void* bo, int64_t rows, int C, int64_t rows_per_batch, float eps, float* stats_out,
+                           float stats_eps, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * hallo_frames_to_uint8: decoded frames, planar fp32 [frames, channels, hw] in [0, 1], to interleaved uint8

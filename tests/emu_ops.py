@@ -77,7 +77,17 @@ def _store(v, out, like_dtype, out_f32=False):
 
 def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, act=ACT_NONE, geglu=False, bias2=None,
          bias2_rows_per_group=0, out_f32=False, bias_per_row=False, lead_cols=0, lead_alpha=1.0, ln_colsum=None,
-         ln_eps=1e-5, ln_stats=None):
+         ln_eps=1e-5, ln_stats=None, row_parts=False):
+    if row_parts:
+        # hallo_gemm_desc.row_parts: (sum, sum of squares) of the ROUNDED output rows per 64-column block, [M][ceil(N / 64)][2]
+        assert not geglu and not out_f32
+        y = gemm(a, w, bias, out=out, residual=residual, rowscale=rowscale, alpha=alpha, act=act, bias2=bias2,
+                 bias2_rows_per_group=bias2_rows_per_group, bias_per_row=bias_per_row, lead_cols=lead_cols, lead_alpha=lead_alpha,
+                 ln_colsum=ln_colsum, ln_eps=ln_eps, ln_stats=ln_stats)
+        M_, N_ = y.shape
+        P = (N_ + 63) // 64
+        yf = F.pad(y.float(), (0, P * 64 - N_)).view(M_, P, 64)
+        return y, real_ops.RowParts(torch.stack([yf.sum(-1), (yf * yf).sum(-1)], dim=-1).contiguous(), P, M_, N_)
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == a.shape[1]
     assert a.shape[1] % 8 == 0 and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0, "K / lda / ldb must be multiples of 8"
     M = a.shape[0]
@@ -88,7 +98,14 @@ def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, 
     if ln_colsum is not None:
         assert ln_colsum.dtype == torch.float32 and ln_colsum.numel() == w.shape[0]
         assert not out_f32 and not bias_per_row
-        if ln_stats is not None:
+        if isinstance(ln_stats, real_ops.RowParts):
+            # hallo_gemm_desc.ln_parts: partial (sum, sum of squares) over the K columns of A, reduced in slot order
+            K_ = a.shape[1]
+            assert ln_stats.rows == M and ln_stats.cols == K_ and tuple(ln_stats.sums.shape) == (M, ln_stats.parts, 2)
+            sm, sq = ln_stats.sums[:, :, 0].sum(1, keepdim=True), ln_stats.sums[:, :, 1].sum(1, keepdim=True)
+            mean = sm / K_
+            rstd = torch.rsqrt((sq / K_ - mean * mean).clamp_min(0.0) + ln_eps)
+        elif ln_stats is not None:
             assert ln_stats.dtype == torch.float32 and ln_stats.numel() == 2 * M
             mean, rstd = ln_stats.view(M, 2)[:, 0:1], ln_stats.view(M, 2)[:, 1:2]
         else:
@@ -244,10 +261,20 @@ def row_stats(x2d, eps=1e-5):
     return torch.stack([xf.mean(dim=1), torch.rsqrt(xf.var(dim=1, unbiased=False) + eps)], dim=1).contiguous()
 
 
-def ln_stats(x2d, n_out, eps=1e-5, *, geglu=False, bias2_rows_per_group=0, lead_cols=0):
+def ln_stats(x2d, n_out, eps=1e-5, *, geglu=False, bias2_rows_per_group=0, lead_cols=0, given=None):
     """ops.ln_stats asks the LIBRARY whether its row-stationary kernel takes the problem; the emulation always hands the
-    statistics over (both routes compute the same LayerNorm), so the CPU host-logic suite never loads libhallo_amd.so."""
-    return row_stats(x2d, eps)
+    statistics over (both routes compute the same LayerNorm), so the CPU host-logic suite never loads libhallo_amd.so.
+    given: what the producer of x2d delivered (round 5) -- used as is, so that the host plumbing (which producer feeds which
+    consumer, row / column bookkeeping across the motion-frame drop) is what the oracle comparison checks."""
+    return given if given is not None else row_stats(x2d, eps)
+
+
+def producer_stats():
+    return True
+
+
+def wants_stats(M, n_out, K, *, geglu=False, bias2_rows_per_group=0, lead_cols=0):
+    return True
 
 
 def ff320_enabled(rows):
@@ -328,7 +355,10 @@ def frames_to_uint8(x, out=None):
     return u8
 
 
-def face_xattn(x, sg, g, b, owp, bo, rows_per_batch, eps, out=None):
+def face_xattn(x, sg, g, b, owp, bo, rows_per_batch, eps, out=None, stats_eps=None):
+    if stats_eps is not None:       # hallo_face_xattn_stats: (mean, rstd) of the rounded OUTPUT rows
+        y = face_xattn(x, sg, g, b, owp, bo, rows_per_batch, eps, out=out)
+        return y, row_stats(y.contiguous(), stats_eps)
     rows, Cd = x.shape
     assert x.is_contiguous() and sg.shape[-2:] == (32, Cd) and owp.shape[-2:] == (Cd, 32) and Cd % 32 == 0
     assert rows_per_batch % 32 == 0
@@ -364,7 +394,7 @@ def lerp_rows(x, out_rows):
 
 
 EMULATED = ("dtype_code", "set_option", "get_option", "options_fingerprint", "publish_constant", "Scratch", "gemm", "gemm_batched", "conv3x3", "attention", "temporal_attention",
-            "groupnorm", "layernorm", "row_stats", "ln_stats", "ff320_enabled", "softmax_rows", "copy2d", "nchw_to_nhwc", "nhwc_to_nchw_f32",
+            "groupnorm", "layernorm", "row_stats", "ln_stats", "producer_stats", "wants_stats", "ff320_enabled", "softmax_rows", "copy2d", "nchw_to_nhwc", "nhwc_to_nchw_f32",
             "timestep_embedding", "cfg_ddim_step", "frames_to_uint8", "face_xattn", "w2v_conv0_gn_gelu", "lerp_rows")
 
 

@@ -150,6 +150,88 @@ def test_gemm_fused_layernorm(dtype, M, N, K, report):
     _check(f"gemm_ln_res[{M},{N},{K}]", out, ref + res.float(), dtype, report)
 
 
+def _row_parts_of(t):
+    """torch statement of hallo_gemm_desc.row_parts for a tensor t [M, N]: (sum, sum of squares) per 64-column block"""
+    from hallo_amd import ops
+    M, N = t.shape
+    P = (N + 63) // 64
+    tf = torch.nn.functional.pad(t.float(), (0, P * 64 - N)).view(M, P, 64)
+    return ops.RowParts(torch.stack([tf.sum(-1), (tf * tf).sum(-1)], dim=-1).contiguous(), P, M, N)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,res", [(8192, 320, 320, True), (65536, 320, 320, True), (1000, 640, 1280, False), (1000, 328, 776, True),
+                                       (4096, 1280, 1280, True), (4608, 1280, 5120, True), (4096, 1280, 3848, True), (70, 64, 64, False)])
+def test_gemm_row_parts_from_the_epilogue(dtype, M, N, K, res, report):
+    """hallo_gemm_desc.row_parts (ABI v7): (sum, sum of squares) of the ROUNDED output rows per 64-column block, written by the
+    128 x 128 kernel's epilogue (1- and 2-stage forms, ragged M, N not a multiple of 64) or, for the shapes the routing gives to
+    the big tile / split-K kernels, by one extra pass -- the same layout either way.  C must not change by a bit."""
+    from hallo_amd import ops
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    a = _rand((M, K), dtype, g)
+    w = _rand((N, K), dtype, g, K ** -0.5)
+    b = _rand((N,), dtype, g, 0.2)
+    r = _rand((M, N), dtype, g) + 0.5 if res else None
+    plain = ops.gemm(a, w, b, residual=r)
+    out, parts = ops.gemm(a, w, b, residual=r, row_parts=True)
+    assert torch.equal(out, plain)
+    ref = _row_parts_of(out)
+    assert parts.parts == ref.parts and tuple(parts.sums.shape) == tuple(ref.sums.shape)
+    scale = ref.sums.abs().amax().item()
+    err = (parts.sums - ref.sums).abs().max().item()
+    report.append({"test": f"gemm_row_parts[{M},{N},{K}]", "dtype": str(dtype), "max_abs_err": err, "ref_absmax": scale,
+                   "kernel": ops.get_option("last_gemm_kernel")})
+    assert err <= 2e-5 * scale + 1e-5, (err, scale)
+    # the forced extra-pass form (hallo_set_option("row_parts", 0)) gives the same numbers in the same layout
+    old = ops.set_option("row_parts", 0)
+    try:
+        out2, parts2 = ops.gemm(a, w, b, residual=r, row_parts=True)
+    finally:
+        ops.set_option("row_parts", old)
+    assert torch.equal(out2, plain) and torch.equal(parts2.sums, parts.sums)      # same summation tree: same bits
+
+
+@pytest.mark.parametrize("variant", [6, 4, 5])
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(4096, 960, 320), (1000, 328, 640), (4608, 3840, 1280), (70, 1920, 1280)])
+def test_gemm_fused_layernorm_from_row_parts(variant, dtype, M, N, K, report):
+    """hallo_gemm_desc.ln_parts (ABI v7): the LayerNorm-fused projection takes its rows' statistics as the PRODUCER's partial
+    sums [M][K / 64][2] and reduces them in its prologue (128 x 128 kernel: variant 6 = auto; big tile: 4 / 5 forced), against
+    layer_norm(x) @ W^T + b in fp32; end to end: a producer GEMM's row_parts feeding the consumer."""
+    from hallo_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + variant)
+    x = _rand((M, K), dtype, g) * 1.5 + 0.7
+    gamma = (1.0 + 0.1 * torch.randn((K,), generator=g)).to(dtype).to(_dev())
+    beta = _rand((K,), dtype, g, 0.1)
+    w = _rand((N, K), dtype, g, K ** -0.5)
+    b = _rand((N,), dtype, g, 0.1)
+    wf, cs, bf = ops.fold_layernorm(gamma, beta, w, b)
+    ref = torch.nn.functional.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5) @ w.float().t() + b.float()
+    old = ops.set_option("gemm_variant", variant)
+    try:
+        out = ops.gemm(x, wf, bf, ln_colsum=cs, ln_eps=1e-5, ln_stats=_row_parts_of(x))
+        kern = ops.get_option("last_gemm_kernel")
+        _check(f"gemm_ln_parts[{M},{N},{K},v{variant}]", out, ref, dtype, report)
+        lead = (N // 3) // 8 * 8
+        out = ops.gemm(x, wf, bf, ln_colsum=cs, ln_eps=1e-5, ln_stats=_row_parts_of(x), lead_cols=lead, lead_alpha=0.25)
+        ref2 = ref.clone()
+        ref2[:, :lead] *= 0.25
+        _check(f"gemm_ln_parts_lead[{M},{N},{K},v{variant}]", out, ref2, dtype, report)
+        # producer -> consumer: x2 = a @ wp^T + r written by a GEMM whose epilogue emits the parts the next GEMM normalises with
+        a = _rand((M, 320), dtype, g)
+        wp = _rand((K, 320), dtype, g, 320 ** -0.5)
+        r = _rand((M, K), dtype, g) + 0.3
+        x2, parts = ops.gemm(a, wp, None, residual=r, row_parts=True)
+        out = ops.gemm(x2, wf, bf, ln_colsum=cs, ln_eps=1e-5, ln_stats=parts)
+        ref3 = torch.nn.functional.layer_norm(x2.float(), (K,), gamma.float(), beta.float(), 1e-5) @ w.float().t() + b.float()
+        _check(f"gemm_ln_parts_chain[{M},{N},{K},v{variant}]", out, ref3, dtype, report)
+        out_rs = ops.gemm(x2, wf, bf, ln_colsum=cs, ln_eps=1e-5, ln_stats=ops.row_stats(x2, 1e-5))
+        assert ((out.float() - out_rs.float()).abs().max() <= 2.0 ** -6 * ref3.abs().max()).item()
+    finally:
+        ops.set_option("gemm_variant", old)
+    report.append({"test": f"gemm_ln_parts_kernel[{M},{N},{K},v{variant}]", "dtype": str(dtype), "kernel": kern})
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,Cd", [(300, 320), (2048, 640)])
 def test_gemm_geglu_fused_layernorm(dtype, M, Cd, report):
@@ -167,6 +249,14 @@ def test_gemm_geglu_fused_layernorm(dtype, M, Cd, report):
     _check(f"geglu_ln[{M},{Cd}]", out, ops_ref.geglu(nh, w, b), dtype, report)
     out = ops.gemm(x, wf, bf, geglu=True, ln_colsum=cs, ln_eps=1e-5, ln_stats=ops.row_stats(x, 1e-5))
     _check(f"geglu_ln_stats[{M},{Cd}]", out, ops_ref.geglu(nh, w, b), dtype, report)
+    # round 5: the statistics as the producer's partial sums (ln_parts), 128 x 128 kernel and forced big tile
+    for variant in (6, 4, 5):
+        old = ops.set_option("gemm_variant", variant)
+        try:
+            out = ops.gemm(x, wf, bf, geglu=True, ln_colsum=cs, ln_eps=1e-5, ln_stats=_row_parts_of(x))
+        finally:
+            ops.set_option("gemm_variant", old)
+        _check(f"geglu_ln_parts[{M},{Cd},v{variant}]", out, ops_ref.geglu(nh, w, b), dtype, report)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -497,11 +587,21 @@ def test_face_xattn_fused(dtype, Cd, heads, rows_pb, nb, report):
     ops.face_xattn(y, sg, gg, bb, owp, bo, rows_pb, 1e-5, out=y)          # in place
     assert torch.equal(y, out)
     # C = 320 / 640 / 1280 run the LDS-staged kernel; the row-per-lane kernel (any C) must give the same bits
-    ops.set_option("xattn_tiled", 0)
+    old = ops.set_option("xattn_tiled", 0)
     try:
         assert torch.equal(ops.face_xattn(x, sg, gg, bb, owp, bo, rows_pb, 1e-5), out)
+        ops.set_option("xattn_tiled", 1)          # (round 5: the default, 2, prefetches the next block at C = 320)
+        assert torch.equal(ops.face_xattn(x, sg, gg, bb, owp, bo, rows_pb, 1e-5), out)
     finally:
-        ops.set_option("xattn_tiled", 1)
+        ops.set_option("xattn_tiled", old)
+    # round 5 (hallo_face_xattn_stats): the output rows' LayerNorm statistics from the kernel's own epilogue -- what
+    # hallo_row_stats(y) gives, without the pass over y; y itself is bit-identical
+    y2, st = ops.face_xattn(x, sg, gg, bb, owp, bo, rows_pb, 1e-5, stats_eps=1e-6)
+    assert torch.equal(y2, out)
+    of = out.float()
+    assert torch.allclose(st[:, 0], of.mean(1), atol=2e-5, rtol=1e-4)
+    assert torch.allclose(st[:, 1], (of.var(1, unbiased=False) + 1e-6).rsqrt(), atol=1e-5, rtol=1e-3)
+    assert torch.allclose(st, ops.row_stats(out, 1e-6), atol=2e-5, rtol=1e-3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -511,6 +511,29 @@ def test_gemm4_epilogue_options(dtype, report):
         ops.set_option("gemm4", g4)
 
 
+def test_gemm4_refuses_k_split_tails_without_a_zeroed_workspace(report):
+    """hallo_gemm_desc.workspace_zeroed (ABI v7): the K-split tail of csrc/gemm4.hip counts arrivals in the last 64 KB of
+    the workspace, which must be zero.  A caller that does not vouch for that (what an ABI v5/v6-style caller with uninitialised
+    scratch amounts to) must never get a split tail -- whole tiles (or another kernel) instead, same result."""
+    from hallo_amd import ops
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 2304, 640, 2560                # hallo_gemm4_schedule: 72 tiles, each K loop dealt over 2 workgroups (a split tail)
+    x, w, b = _rand((M, K), dtype, g), _rand((N, K), dtype, g, K ** -0.5), _rand((N,), dtype, g, 0.1)
+    g4 = ops.set_option("gemm4", 2)
+    try:
+        out1 = ops.gemm(x, w, b)
+        assert (ops.get_option("last_gemm_kernel") % 1000) // 100 == 6 and ops.get_option("last_gemm_splits") > 1000   # a split tail
+        ops.WS_ZEROED = 0
+        out0 = ops.gemm(x, w, b)
+        assert ops.get_option("last_gemm_splits") < 1000                                                              # none now
+    finally:
+        ops.WS_ZEROED = 1
+        ops.set_option("gemm4", g4)
+    _check("gemm4[no split tail without a zeroed workspace]", out0, x.float() @ w.float().t() + b.float(), dtype, report)
+    _check("gemm4[split tail]", out1, x.float() @ w.float().t() + b.float(), dtype, report)
+
+
 def test_gemm4_auto_rule(report):
     """The routing rule of launch_gemm (csrc/gemm.hip): gemm4.hip takes the one-round problems with K >= 2560 -- ff.net[2] of the
     16 x 16 level -- and nothing else (hot and cold A/B: profiles/r4_gemm4_ab.txt, profiles/r4_gemm4_e2e_ab.json)."""

@@ -341,7 +341,7 @@ static void run_gemm_case(const GemmOpts& g, Timer& tm) {
   static void* ws = nullptr;                       // split-K scratch, as hallo_amd/ops.py hands one to every GEMM
   const long ws_bytes = 256L << 20;
   if (!ws) { CK(hipMalloc(&ws, ws_bytes)); CK(hipMemset(ws, 0, ws_bytes)); }      // zero-initialised: the stream-K kernel's arrival counters
-  d.workspace = ws; d.workspace_bytes = ws_bytes;
+  d.workspace = ws; d.workspace_bytes = ws_bytes; d.workspace_zeroed = 1;
   const bool fused_stats = g.ln && hallo_gemm_fuses_row_stats(g.M, g.N, g.K, g.geglu, 0, 0);
   if (g.ln && !fused_stats) d.ln_stats = stats;
   auto launch = [&] {
@@ -511,13 +511,13 @@ static int cmd_ff(int argc, char** argv) {
   // the two-GEMM path
   hallo_gemm_desc d1; memset(&d1, 0, sizeof d1);
   d1.A = X; d1.B = W1f; d1.C = Hb; d1.M = M; d1.N = I; d1.K = C; d1.lda = C; d1.ldb = C; d1.ldc = I; d1.batch = 1; d1.bias = b1f; d1.alpha = 1.0f;
-  d1.geglu = 1; d1.dtype = dt; d1.lead_alpha = 1.0f; d1.workspace = ws; d1.workspace_bytes = ws_bytes;
+  d1.geglu = 1; d1.dtype = dt; d1.lead_alpha = 1.0f; d1.workspace = ws; d1.workspace_bytes = ws_bytes; d1.workspace_zeroed = 1;
   float* stats = dalloc<float>((long)M * 2);
   const bool fused_stats = ln && hallo_gemm_fuses_row_stats(M, I, C, 1, 0, 0);
   if (ln) { d1.ln_colsum = cs; d1.ln_eps = 1e-5f; if (!fused_stats) d1.ln_stats = stats; }
   hallo_gemm_desc d2; memset(&d2, 0, sizeof d2);
   d2.A = Hb; d2.B = W2; d2.C = Y2; d2.M = M; d2.N = C; d2.K = I; d2.lda = I; d2.ldb = I; d2.ldc = C; d2.batch = 1; d2.bias = b2; d2.alpha = 1.0f;
-  d2.residual = X; d2.ldr = C; d2.dtype = dt; d2.lead_alpha = 1.0f; d2.workspace = ws; d2.workspace_bytes = ws_bytes;
+  d2.residual = X; d2.ldr = C; d2.dtype = dt; d2.lead_alpha = 1.0f; d2.workspace = ws; d2.workspace_bytes = ws_bytes; d2.workspace_zeroed = 1;
   auto pair = [&] { if (ln && !fused_stats) HK(hallo_row_stats(X, stats, M, C, 1e-5f, dt, nullptr)); HK(hallo_gemm(&d1, nullptr)); HK(hallo_gemm(&d2, nullptr)); };
   auto fusedk = [&] { HK(hallo_ff320(X, C, X, C, Y, C, dimg, b2, M, ln ? 1 : 0, 1e-5f, dt, nullptr)); };
   pair(); CK(hipDeviceSynchronize());
