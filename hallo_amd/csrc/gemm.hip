@@ -881,6 +881,7 @@ static int launch_gemm_impl(GemmArgs a, bool conv, bool geglu, int batch, void* 
   int v = a.vec_ok ? g_gemm_variant : 0;
   const bool lnf = a.ln_colsum != nullptr;      // fused LayerNorm: 128x128 LDS-DMA kernel only, no split-K
   const bool gelu = a.act >= ACT_GELU;          // GELU epilogues (wav2vec2 front-end): own instantiation of the 128x128 kernel
+  g_last_splits = 1;                            // (before the row-stationary early returns: they never split)
   if (g_gemm_rs >= 2 && v >= 3 && a.vec_ok && gemm_rs2_eligible(a, conv, geglu, batch)) {
     // 5xx: gemm_rs2_kernel (K = 320, pipelined epilogue): + 10 * mode (0 gemm, 2 geglu) + 1, + 1000 with LayerNorm
     g_last_kernel = 500 + (geglu ? 20 : 0) + 1 + (lnf ? 1000 : 0);
