@@ -366,9 +366,10 @@ def cpu_baseline(frames, steps_ddim, budget_s=150.0):
     return best
 
 
+# (the throughput kernel routing loses with TWO evaluations in flight: 5.87 against 6.03, and taken one option at a time only the row-
+# stationary GEMMs matter -- gemm_rs = 0 costs 5 %; decode overlap alone is worth +-0: profiles/r5_configs2_ab.json, tools/r5_configs2_ab.py)
 CONFIGS2_VARIANTS = (("sequential", dict(routing="latency"), {}),
-                     ("overlapped", dict(routing="latency", cfg_split=True), dict(overlap_decode=True)),
-                     ("overlapped_throughput_routing", dict(routing="throughput", cfg_split=True), dict(overlap_decode=True)))
+                     ("overlapped", dict(routing="latency", cfg_split=True), dict(overlap_decode=True)))
 
 
 def configs2_leg(pipe, audioproj, dev, S, Fr, n_clips, make_scheduler, dtype, variants=CONFIGS2_VARIANTS):
