@@ -38,6 +38,10 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # it enqueues and goes to sleep on the slot's blocking event: process CPU 1.68 -> 1.40 cores per rank, frames/s +1 % (profiles/
 # r5_host_aql_queue.json).  Read by the runtime at first use: must be set before HIP initialises.
 os.environ.setdefault("ROC_AQL_QUEUE_SIZE", "65536")
+# The runtime recycles completion signals from a pool of 64; with 17 000+ dispatches per clip its helper thread spun on that pool for
+# ~630 ms of CPU per 0.9 s clip.  A pool of 4096 (64 KB of signals) stops it: process CPU per rank 0.86 -> 0.16 cores, frames/s
+# unchanged (profiles/r5_host_cpu_per_rank.json).  Together with the sleeping slot wait below: 1.68 -> 0.16 cores per rank since round 4.
+os.environ.setdefault("ROC_SIGNAL_POOL_SIZE", "4096")
 
 import torch  # noqa: E402
 
@@ -443,6 +447,7 @@ def main():
     ap.add_argument("--configs2-clips", type=int, default=3)
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the one-clip-at-a-time reference leg (rank 0, N = 1; ~5 s)")
     ap.add_argument("--latency-routing", action="store_true", help="A/B: keep the one-clip kernel routing (library defaults) with clips in flight")
+    ap.add_argument("--spin-slot-wait", action="store_true", help="A/B: wait for a slot's previous clip with hipEventSynchronize (spins) instead of query + sleep")
     ap.add_argument("--no-slot-wait", action="store_true", help="A/B: do not wait (blocking event) for a slot's previous clip before enqueuing its next one")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: hallo_set_option(NAME, VALUE) before the pipeline is built (e.g. gemm4=0); recorded in config.options")
@@ -570,6 +575,7 @@ def main():
     # sleeps instead of spinning inside a launch call against a full hardware queue: with 8 ranks sharing one host that is 8 cores
     # given back); the clips of the other slots keep the GPU busy meanwhile.
     slot_done = [None] * (1 if dry else len(pipes))
+    wait_cpu = [0.0]
 
     # one int64 per timed clip: the sum of the bit patterns of its fp32 frames, written by a reduction on the clip's own stream
     # (50 MB read, ~15 us of an 800 ms clip) and compared AFTER the timed region with the same clips run alone
@@ -578,7 +584,16 @@ def main():
     def run(d, exchange=True, slot=0, chk_out=None):
         if not dry and len(pipes) > 1:
             if slot_done[slot] is not None and not args.no_slot_wait:
-                slot_done[slot].synchronize()
+                c0 = time.thread_time()
+                if args.spin_slot_wait:
+                    slot_done[slot].synchronize()
+                else:
+                    # hipEventSynchronize SPINS on this runtime even for an event created with the blocking-sync flag: 498 of the
+                    # launch thread's 643 ms of CPU per clip were burnt inside this wait (profiles/r5_host_cpu_per_rank.json).  Poll and
+                    # sleep instead: the other two slots keep the GPU busy for hundreds of ms, a millisecond of slack costs nothing.
+                    while not slot_done[slot].query():
+                        time.sleep(0.001)
+                wait_cpu[0] += time.thread_time() - c0        # CPU the launch thread spends inside the wait
             with torch.cuda.stream(streams[slot]):
                 r_ = run_on(d, exchange, pipes[slot], hosts[slot], chk_out)
                 if slot_done[slot] is None:
@@ -648,12 +663,14 @@ def main():
     host_s = 0.0
     cpu0 = time.process_time()
     thr0 = time.thread_time()
+    wait_cpu[0] = 0.0
     tcpu0 = thread_cpu_times()
     for i in range(args.steps):
         th = time.perf_counter()
         run(inputs[args.warmup + i], slot=i % n_slots, chk_out=None if dry else chk[i:i + 1])
         host_s += time.perf_counter() - th      # wall time inside the enqueue calls of a clip: includes the runtime's back-pressure
     cpu_main_s = time.thread_time() - thr0      # CPU time of the launch thread alone
+    cpu_wait_s = wait_cpu[0]
     cpu_s = time.process_time() - cpu0          # when the hardware queue is full (25 replays x ~690 packets); CPU time of the process
     fence()
     elapsed = time.perf_counter() - t0
@@ -695,6 +712,7 @@ def main():
                    "host_wall_in_enqueue_calls_ms_per_clip": round(host_s / args.steps * 1e3, 1),
                    "host_cpu_ms_per_clip": round(cpu_s / args.steps * 1e3, 1),
                    "host_cpu_launch_thread_ms_per_clip": round(cpu_main_s / args.steps * 1e3, 1),
+                   "host_cpu_launch_thread_inside_slot_waits_ms_per_clip": round(cpu_wait_s / args.steps * 1e3, 1),
                    "host_cores_busy_per_rank": round(cpu_s / elapsed, 2),
                    "host_cpu_ms_per_clip_by_thread": by_thread,
                    "host_cores_per_rank": len(pinned) if pinned else len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,

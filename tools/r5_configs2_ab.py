@@ -2,6 +2,7 @@
 BASELINE configs[2] through generate_video, one option of ops.THROUGHPUT_OPTIONS at a time on top of the library defaults."""
 import json, os, sys
 os.environ.setdefault("ROC_AQL_QUEUE_SIZE", "65536")
+os.environ.setdefault("ROC_SIGNAL_POOL_SIZE", "4096")
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
