@@ -10,20 +10,23 @@ A "step" = one clip per rank.  bf16 storage, fp32 accumulation, random-init weig
 architecture, synthetic inputs.  The K timed clips of a rank are independent (each carries its own reference / motion
 frames, the clip-parallel contract of DESIGN section 8) and are issued back to back over `--inflight` (default 3) pipeline
 objects + HIP streams sharing the weights, so that up to three clips overlap on the GPU (the 16x16 / 8x8 levels and the tail of
-every launch leave CUs idle that another clip's kernels fill), with the kernel routing for that regime
-(hallo_amd.ops.THROUGHPUT_OPTIONS): 19.33 frames/s against 16.66 one clip at a time on the same box (profiles/
-r4_bench_other_runs.json).  Frames are byte-identical to one-at-a-time execution under the same routing
-(tests/test_models_gpu.py::test_pipeline_clips_in_flight_are_byte_identical); the whole 25-step trajectory is parity-tested under
-both routings (tests/test_full_size_gpu.py::test_full_pipeline_trajectory).
+every launch leave CUs idle that another clip's kernels fill), each pipeline with the kernel routing for that regime
+(FaceAnimatePipeline(routing="throughput") = hallo_amd.ops.THROUGHPUT_OPTIONS) and its own launch scratch.
 `ms_per_step` = timed wall time / K (throughput); `clip_latency_ms` = that x clips in flight.
+
+Legs after the timed region (same process, same box), each one object on the JSON line:
+  inflight_identity    every rank: the first timed clips again, ALONE; the int64 sum of the frames' bit patterns must equal what the
+                       timed clip left behind while three clips overlapped, else the line carries "INVALID"
+  one_clip_at_a_time   rank 0, N = 1: three clips one after the other with the library-default routing (rounds 1-3 executed this way)
+  configs2             rank 0, N = 1: BASELINE.json configs[2] = the reference's default run (40 steps, CFG 3.5) as ONE video of 3
+                       sequential clips through animate.video.generate_video, sequential and with cfg_split + overlap_decode
+  kernels / roofline / attention_families   rank 0: an instrumented eager clip, every operator launch bracketed by events on the
+                       launch stream, per kernel family and per kernel symbol
+  cpu_baseline         rank 0, N = 1: the CPU oracle on this box's host cores (child process, bounded)
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
-
-Extra objects on the JSON line: `roofline` (dominant kernel family, measured with events on the launch
-stream in an instrumented extra clip), `cpu_baseline` (the CPU oracle timed on this box's host cores,
-rank 0 at N = 1), `kernels` (per-family time / achieved rate of the instrumented clip).
 """
 import argparse
 import json

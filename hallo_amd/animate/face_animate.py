@@ -21,6 +21,7 @@ Deviation from the reference, on purpose: `guidance_scale <= 1` works (the refer
 tensor unconditionally, face_animate.py:377-379, and then dies in the audio cross-attention -- SURVEY F5);
 here nothing is doubled without CFG.  BASELINE configs[1] (25 steps, no CFG) needs this.
 """
+import contextlib
 from dataclasses import dataclass
 
 import torch
@@ -295,14 +296,14 @@ class FaceAnimatePipeline:
         """One CFG evaluation as two B = 1 evaluations: uncond (rows 0..Fr of every [2 Fr, ...] tensor, bank rows 0..2, no bank
         segment in the spatial self-attention) on the auxiliary stream with its own launch scratch, cond (rows Fr.., motion-frame
         features = bank rows 4..5, reference features ALTERNATING between bank rows 0 and 3 over the frames: the reference tiles
-        the bank over the batch axis, mutual_self_attention.py:235-247) on the current stream; both write their half of `v_out`; the current stream then waits for the auxiliary one, so the
-        caller's fused CFG + DDIM kernel sees both halves.  graphed: replay (capture on first use) each half's hipGraph."""
+        the bank over the batch axis, mutual_self_attention.py:235-247) on the current stream; both write their half of `v_out`;
+        the current stream then waits for the auxiliary one, so the caller's fused CFG + DDIM kernel sees both halves.
+        graphed: replay (capture on first use) each half's hipGraph."""
         den = self.denoising_unet
         on_gpu = self.device.type == "cuda"
         if on_gpu:
             main, aux = torch.cuda.current_stream(), self.aux_stream
             aux.wait_stream(main)           # x_in (the previous DDIM update) and this clip's banks / constants are ready
-        import contextlib
         for hi, flag in enumerate((SKIP_BANK, False)):
             hf, rows = halves[hi], slice(hi * Fr, (hi + 1) * Fr)
             with (torch.cuda.stream(aux if hi == 0 else main) if on_gpu else contextlib.nullcontext()), \
