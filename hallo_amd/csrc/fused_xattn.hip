@@ -325,13 +325,16 @@ using namespace hallo;
 // hallo_set_option("xattn_tiled", 0 | 1 | 2): LDS-staged face cross-attention for C = 320 / 640 / 1280; 2 (default, round 5): next-block prefetch at
 // C = 320 (65536 rows: 29.8-32.0 -> 24.5-25.6 us, 73728 rows: 31.8 -> 26.4; profiles/r5_prefetch_ab.json)
 static int g_xattn_tiled = 2;
+static int g_xattn_cap = 0;      // hallo_set_option("xattn_cap", n): resident-workgroup cap of the tiled kernel at C = 640 / 1280 (0 = 512; A/B)
 extern "C" int hallo_set_option_xattn(const char* name, int value) {
   if (name && !strcmp(name, "xattn_tiled")) { if (value < 0 || value > 2) return -22; g_xattn_tiled = value; return 0; }
+  if (name && !strcmp(name, "xattn_cap")) { if (value < 0 || value > 4096) return -22; g_xattn_cap = value; return 0; }
   return -2;
 }
 
 extern "C" int hallo_get_option_xattn(const char* name) {
   if (name && !strcmp(name, "xattn_tiled")) return g_xattn_tiled;
+  if (name && !strcmp(name, "xattn_cap")) return g_xattn_cap;
   return -22;
 }
 
@@ -351,7 +354,7 @@ extern "C" int hallo_face_xattn_stats(const void* x, void* y, const void* sg, co
   if (g_xattn_tiled && (C == 320 || C == 640 || C == 1280) && (dtype == DT_F16 || dtype == DT_BF16)) {
     // persistent: the workgroups a CU keeps resident walk the 32-row blocks (the per-batch constants load once per workgroup)
     const int nblocks = (int)grid.x;
-    const int cap = C == 320 ? 768 : 512;             // resident workgroups: 3 per CU at C = 320 (160 registers, 39 KB), 2 at 640, 1 at 1280
+    const int cap = C == 320 ? 768 : (g_xattn_cap > 0 ? g_xattn_cap : 512);   // resident workgroups: 3 per CU at C = 320 (160 registers, 39 KB), 2 at 640, 1 at 1280
     const dim3 pg((unsigned)(nblocks < cap ? nblocks : cap));
     // the prefetching form only where a workgroup walks several blocks (C = 320 at 64 x 64: 2048 blocks over <= 512 workgroups of
     // 226 registers, two per SIMD); at C = 640 / 1280 every workgroup has one block and the extra registers would spill
