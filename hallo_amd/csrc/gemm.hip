@@ -532,10 +532,11 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 || MODE == 3 || E
     // round trip; a per-row loop of dependent loads cost 8-13 us per launch), then thread r reduces row r in slot order.
     const int P2 = p.ln_parts * 2;
     const int rows = min(BM, p.M - m0);
-    const int nvec = (rows * P2 + 3) >> 2;                 // m0 * P2 floats is a multiple of 256 floats: 16-byte aligned
+    const int nflt = rows * P2, nvec = nflt >> 2;           // whole 16-byte pieces, then the (<= 3 floats) tail: nothing is read past the rows' partials
     const f32x4* src = reinterpret_cast<const f32x4*>(p.ln_stats + (long)m0 * P2);
     f32x4* stg = reinterpret_cast<f32x4*>(smem);
     for (int i = tid; i < nvec; i += 256) stg[i] = src[i];
+    if (tid < (nflt & 3)) reinterpret_cast<float*>(smem)[nvec * 4 + tid] = p.ln_stats[(long)m0 * P2 + nvec * 4 + tid];
     __syncthreads();
     if (tid < BM) {
       const float* pr = reinterpret_cast<const float*>(smem) + min(tid, rows - 1) * P2;

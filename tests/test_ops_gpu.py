@@ -193,7 +193,7 @@ def test_gemm_row_parts_from_the_epilogue(dtype, M, N, K, res, report):
 
 @pytest.mark.parametrize("variant", [6, 4, 5])
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(4096, 960, 320), (1000, 328, 640), (4608, 3840, 1280), (70, 1920, 1280)])
+@pytest.mark.parametrize("M,N,K", [(4096, 960, 320), (1000, 328, 640), (4608, 3840, 1280), (70, 1920, 1280), (1001, 960, 320)])
 def test_gemm_fused_layernorm_from_row_parts(variant, dtype, M, N, K, report):
     """hallo_gemm_desc.ln_parts (ABI v7): the LayerNorm-fused projection takes its rows' statistics as the PRODUCER's partial
     sums [M][K / 64][2] and reduces them in its prologue (128 x 128 kernel: variant 6 = auto; big tile: 4 / 5 forced), against
