@@ -75,7 +75,7 @@ def generate_video(pipeline, audioproj, source_image_pixels, source_image_face_r
                     pixel_values_lip_mask=lip_mask, width=img_size[0], height=img_size[1], video_length=clip_length,
                     num_inference_steps=inference_steps, guidance_scale=cfg_scale, generator=generator,
                     motion_scale=motion_scale)
-        if overlap_decode and on_gpu and 0 < n_motion_frames < clip_length:
+        if overlap_decode and 0 < n_motion_frames < clip_length:
             prev, host = _decode_overlapped(pipeline, pipeline(decode=False, **call), clip_length, n_motion_frames, output)
             results.append(host)
             if on_clip is not None:
@@ -98,7 +98,7 @@ def generate_video(pipeline, audioproj, source_image_pixels, source_image_face_r
             on_clip(t, times)
     if on_gpu:
         torch.cuda.current_stream().synchronize()
-        if overlap_decode:
+        if overlap_decode and 0 < n_motion_frames < clip_length:
             pipeline.decode_side[0].synchronize()
     if output == "uint8" and on_gpu:
         return torch.cat(results, dim=0)[:audio_length]
@@ -117,20 +117,25 @@ def _decode_overlapped(pipeline, lat5, clip_length, n_motion, output):
     lat = lat5[0].permute(1, 2, 3, 0).reshape(Fr * L, C).contiguous()
     nh = Fr - n_motion
     tail, H, W = pipeline.decode_latents_device(lat[nh * L:], n_motion, h, w)               # [n_motion, 3, H*W] in [0, 1]
-    main = torch.cuda.current_stream()
-    side, scratch = pipeline.decode_side
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
+
+    def rest(scratch):
         head, _, _ = pipeline.decode_latents_device(lat[:nh * L], nh, h, w, scratch=scratch)
         frames = torch.cat([head, tail], dim=0)                                                # [F, 3, H*W]
         if output == "uint8":
-            dev_out = ops.frames_to_uint8(frames).view(Fr, H, W, 3)
-        else:
-            dev_out = frames.view(Fr, 3, H, W).permute(1, 0, 2, 3).unsqueeze(0)
-        host = torch.empty(dev_out.shape, dtype=dev_out.dtype).pin_memory()
-        host.copy_(dev_out, non_blocking=True)
-    for t_ in (lat, tail):
-        t_.record_stream(side)            # allocated on the main stream, read by the decode stream
+            return ops.frames_to_uint8(frames).view(Fr, H, W, 3)
+        return frames.view(Fr, 3, H, W).permute(1, 0, 2, 3).unsqueeze(0)
+    if lat.is_cuda:
+        main = torch.cuda.current_stream()
+        side, scratch = pipeline.decode_side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dev_out = rest(scratch)
+            host = torch.empty(dev_out.shape, dtype=dev_out.dtype).pin_memory()
+            host.copy_(dev_out, non_blocking=True)
+        for t_ in (lat, tail):
+            t_.record_stream(side)            # allocated on the main stream, read by the decode stream
+    else:                                     # (CPU: the operator emulation of the test suite -- same order of work, no streams)
+        host = rest(None)
     return tail.view(n_motion, 3, H, W).permute(1, 0, 2, 3).unsqueeze(0), host
 
 

@@ -195,9 +195,12 @@ def test_scheduler_modes(emu):
     assert getattr(cfg, "no_such_key", 7) == 7 and not hasattr(cfg, "no_such_key") and cfg.clip_sample is True
 
 
-def test_sliding_window_driver(emu, oracle):
+@pytest.mark.parametrize("Fr,overlapped", [(2, False), (3, True)], ids=["plain", "cfg_split+overlap_decode"])
+def test_sliding_window_driver(emu, oracle, Fr, overlapped):
     """hallo_amd.animate.video.generate_video (motion-frame carry, audio windowing, one generator stream for all clips,
-    trim to the audio length) vs the oracle driver around the oracle pipeline: 3 clips of 2 frames."""
+    trim to the audio length) vs the oracle driver around the oracle pipeline: 3 clips of 2 frames; round 5: 2 clips of 3 frames
+    with the sequential-path overlaps on -- cfg_split (two B = 1 halves per evaluation) and overlap_decode (the last 2 frames of a
+    clip decoded first and handed to the next clip, the first frame decoded after them, the clip re-assembled in frame order)."""
     from oracle import harness as Hn
     from oracle import hallo_ref as H
     from oracle import driver_ref as D
@@ -205,7 +208,9 @@ def test_sliding_window_driver(emu, oracle):
     from hallo_amd.animate.face_animate import FaceAnimatePipeline, FaceAnimatePipelineOutput
     from hallo_amd.scheduler import DDIMScheduler
     o, n = oracle, _native(oracle)
-    S, Fr, steps, gs, T = 64, 2, 1, 3.5, 7
+    S, steps, gs, T = 64, 1, 3.5, 7
+    nclips = T // Fr
+    alen = nclips * Fr - 1
     g = torch.Generator().manual_seed(77)
     src = torch.rand((3, S, S), generator=g) * 2 - 1
     region = torch.zeros((3, S, S))
@@ -227,16 +232,17 @@ def test_sliding_window_driver(emu, oracle):
         return FaceAnimatePipelineOutput(videos=v)
     with torch.no_grad():
         vo = D.generate_video(oracle_call, lambda a: o["audioproj"](a), src, region, emb, fm, cm, lm, audio, Fr, 2, (S, S),
-                              steps, gs, ms, audio_length=5)
+                              steps, gs, ms, audio_length=alen)
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
                           prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
     pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
-                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched)
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched, cfg_split=overlapped)
     vn = V.generate_video(pipe, n["audioproj"], src, region, emb, fm, cm, lm, audio, clip_length=Fr, n_motion_frames=2,
-                          img_size=(S, S), inference_steps=steps, cfg_scale=gs, motion_scale=ms, audio_length=5)
-    assert vn.shape == vo.shape == (3, 5, S, S)
-    for c in range(3):          # later clips inherit the earlier ones' (tiny) differences through the motion frames
-        assert Hn.psnr(vn[:, 2 * c: 2 * c + 2], vo[:, 2 * c: 2 * c + 2]) > 55.0, c
+                          img_size=(S, S), inference_steps=steps, cfg_scale=gs, motion_scale=ms, audio_length=alen,
+                          overlap_decode=overlapped)
+    assert vn.shape == vo.shape == (3, alen, S, S)
+    for c in range(nclips):     # later clips inherit the earlier ones' (tiny) differences through the motion frames
+        assert Hn.psnr(vn[:, Fr * c: Fr * c + Fr], vo[:, Fr * c: Fr * c + Fr]) > 55.0, c
 
 
 @pytest.mark.parametrize("guidance", [3.5, 1.0])
