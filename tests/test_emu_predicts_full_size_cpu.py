@@ -31,7 +31,7 @@ def test_full_size_bodies_replay(Fz, dtype):
     if dtype == torch.bfloat16:                # round 5: the in-flight identity test's "alone" half (inputs, routing attribute, scratch scope)
         Fz.test_clips_in_flight_identity_at_the_benchmarked_configuration(rep)
     Fz.test_zz_release_cache(rep)
-    assert len(rep) == 1 + len(Fz.CASES) + 2 + 2 + 2 * len(Fz.TRAJ) + 2 and all(r["arch"] == "small" for r in rep)
+    assert len(rep) == 1 + len(Fz.CASES) + 2 + 2 + 3 * len(Fz.TRAJ) + 3 and all(r["arch"] == "small" for r in rep)
 
 
 def test_round_both_is_exact_in_both_types():

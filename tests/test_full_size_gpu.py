@@ -494,7 +494,9 @@ def _traj_oracle_live(name, progress=None):
             progress(i, int(t))
     vid = H.animate(o["vae"], o["reference_unet"], o["denoising_unet"], o["face_locator"], o["imageproj"], H.make_scheduler(),
                     *args, motion_scale=d["motion_scale"], latents=lat, callback=cb)
-    return dict(timesteps=torch.tensor(ts, dtype=torch.int32), latents=torch.stack(kept), video=vid[:, :, c["frames"]].contiguous())
+    from oracle import driver_ref as D
+    return dict(timesteps=torch.tensor(ts, dtype=torch.int32), latents=torch.stack(kept), video=vid[:, :, c["frames"]].contiguous(),
+                video_u8=torch.from_numpy(D.frames_to_uint8(vid[0])).float())
 
 
 def _traj_oracle(name):
@@ -576,6 +578,24 @@ def test_full_pipeline_trajectory(dtype, name, routing, report):
                    "arch": ARCH, "psnr_db": p, "tol_psnr_db": 35.0, "frames_compared": c["frames"], "kernel_routing": routing_name})
     print("PSNR", p)
     assert p >= 35.0
+    if "video_u8" in ref:
+        # round 5: ALL frames, as the product's actual output -- the uint8 video bytes (hallo/utils/util.py:308-312) -- against the
+        # oracle's bytes: PSNR over the 16 frames (the oracle side is quantised: 58.9 dB floor) and the share of bytes within one
+        # step of the oracle's
+        from oracle import driver_ref as D
+        gold = ref["video_u8"].to(torch.uint8)                                          # (F, H, W, 3)
+        mine = torch.from_numpy(D.frames_to_uint8(vid_n[0]))
+        assert tuple(mine.shape) == tuple(gold.shape) == (c["Fr"], c["S"], c["S"], 3)
+        p16 = Hn.psnr(vid_n[0].permute(1, 2, 3, 0), gold.float() / 255.0)
+        within1 = float(((mine.int() - gold.int()).abs() <= 1).float().mean())
+        equal = float((mine == gold).float().mean())
+        report.append({"test": f"full_{name}_all_frames_u8[{c['S']}x{c['S']}x{c['Fr']}f,{c['steps']} steps,gs={c['gs']}]", "dtype": str(dtype),
+                       "arch": ARCH, "psnr_db_all_frames_vs_oracle_bytes": p16, "bytes_equal": equal, "bytes_within_1": within1,
+                       "kernel_routing": routing_name})
+        print("all frames: PSNR", p16, "bytes equal", equal, "within 1", within1)
+        # (51-52 dB in bf16 at full width is an error of 0.7 byte steps RMS: ~96 % of the bytes land within one step; the reduced-width
+        # architecture of the CPU replay sits at 44 dB and is only recorded)
+        assert p16 >= 35.0 and (ARCH != "full" or within1 >= (0.99 if dtype == torch.float16 else 0.90))
 
 
 def test_clips_in_flight_identity_at_the_benchmarked_configuration(report):
