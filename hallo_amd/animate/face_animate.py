@@ -126,6 +126,9 @@ class FaceAnimatePipeline:
         for m in (self.vae, self.reference_unet, self.denoising_unet, self.face_locator, self.image_proj):
             m.to(device=device, dtype=dtype)
             m.prepare()
+        # launch scratch, side streams and captured graphs belong to the device they were made on
+        self._scratch = self._scratch_aux = self._aux_stream = self._scratch_decode = self._decode_stream = None
+        self._graphs.clear()
         return self
 
     @property
