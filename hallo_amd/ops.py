@@ -176,8 +176,9 @@ class scratch_scope:
 
 
 def current_scratch(device):
-    if _scratch_stack and _scratch_stack[-1] is not None:
-        return _scratch_stack[-1]
+    for s in reversed(_scratch_stack):            # the innermost scope that names a scratch (a None scope changes nothing)
+        if s is not None:
+            return s
     device = torch.device(device)
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     s = _stream_scratch.get(key)

@@ -222,3 +222,30 @@ def test_rank_core_slices_respect_the_cgroup_quota():
     assert bench.rank_cores(cores, 4, 1, 8) == [32]                                # quota below one core per rank: one core each
     assert bench.rank_cores(list(range(4)), 16, 0, 8) is None                      # fewer cores than ranks: no pinning
     assert bench.rank_cores(list(range(16)), 64, 1, 2) == list(range(8, 16))
+
+
+def test_scratch_scope_selects_the_pipelines_own_scratch():
+    """Round 5: launches enqueued inside `ops.scratch_scope(s)` use `s` whatever the current stream is (so a
+    pipeline's eager launches and its graph captures -- which run on torch's process-wide capture stream -- share ITS buffers and
+    nobody else's); scopes nest and unwind; a None scope falls through to the enclosing one."""
+    from hallo_amd import ops
+
+    class Fake:            # stands in for ops.Scratch (which allocates device memory): the selection logic is host-side
+        def __init__(self, tag):
+            self.splitk, self.tag = tag, tag
+    a, b = Fake("a"), Fake("b")
+    with ops.scratch_scope(a):
+        assert ops.current_scratch("cpu") is a and ops._workspace("cpu") == "a"
+        with ops.scratch_scope(b):
+            assert ops.current_scratch("cpu") is b
+            with ops.scratch_scope(None):
+                assert ops.current_scratch("cpu") is b
+            assert ops.current_scratch("cpu") is b
+        assert ops.current_scratch("cpu") is a
+    assert not ops._scratch_stack
+    try:
+        with ops.scratch_scope(a):
+            raise RuntimeError("x")
+    except RuntimeError:
+        pass
+    assert not ops._scratch_stack          # unwound on exceptions too
