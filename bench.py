@@ -446,14 +446,23 @@ def main():
                          "another clip's kernels.  Throughput metric: the K timed clips are the same work, issued back to back.  Same box, "
                          "same binary, library-default routing: 16.08 frames/s with 1, 17.7 with 2, 17.9 with 3 or 4, 17.6 with 6 "
                          "(profiles/r4_inflight_ab.json); n > 1 also selects the throughput kernel routing (see --latency-routing)")
+    ap.add_argument("--batch-clips", type=int, default=1,
+                    help="independent clips per UNet evaluation: a slot's unit of work is a GROUP of this many clips through "
+                         "FaceAnimatePipeline.call_batch (one denoising loop over K x 16 frames: weights read once for K clips, K x the rows "
+                         "for the tiles of the 16x16 / 8x8 levels, no split-K there); --steps that is not a multiple ends with one smaller group")
     ap.add_argument("--no-configs2", action="store_true", help="skip the configs[2] leg (the reference's default run on the sequential video path; ~40 s)")
     ap.add_argument("--configs2-clips", type=int, default=3)
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the one-clip-at-a-time reference leg (rank 0, N = 1; ~5 s)")
+    ap.add_argument("--throughput-routing", action="store_true", help="A/B: the throughput kernel routing with ONE pipeline in flight (e.g. with --batch-clips)")
     ap.add_argument("--latency-routing", action="store_true", help="A/B: keep the one-clip kernel routing (library defaults) with clips in flight")
     ap.add_argument("--spin-slot-wait", action="store_true", help="A/B: wait for a slot's previous clip with hipEventSynchronize (spins) instead of query + sleep")
     ap.add_argument("--no-slot-wait", action="store_true", help="A/B: do not wait (blocking event) for a slot's previous clip before enqueuing its next one")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: hallo_set_option(NAME, VALUE) before the pipeline is built (e.g. gemm4=0); recorded in config.options")
+    ap.add_argument("--shared-scratch", action="store_true",
+                    help="A/B, TIMING ONLY: every pipeline in flight uses ONE launch scratch (round 4's racy execution: frames are wrong, "
+                         "inflight_identity reports it); isolates what own split-K slabs / GroupNorm scratch cost (VERDICT r5 item 1)")
+    ap.add_argument("--scratch-mb", type=int, default=None, help="A/B: size of every pipeline's split-K slab in MB (default 128)")
     ap.add_argument("--shape-breakdown", action="store_true", help="write gpurun_out/shape_breakdown.json (per op x shape times)")
     ap.add_argument("--fp8-proj", action="store_true",
                     help="BASELINE.json configs[4]'s projection variant: q|k|v / out projections of the denoising UNet's "
@@ -527,11 +536,14 @@ def main():
         # three clips in flight: the kernel routing for throughput (hallo_amd/ops.py THROUGHPUT_OPTIONS: +7 % over the one-clip routing
         # at --inflight 3, -4 % at --inflight 1) -- a property of the pipeline objects (FaceAnimatePipeline(routing=...)), applied
         # around their enqueue calls, not process state; --set-option overrides
-        routing = dict(_ops.THROUGHPUT_OPTIONS if (args.inflight > 1 and not args.latency_routing) else _ops.LATENCY_OPTIONS)
+        thr_routing = (args.inflight > 1 or args.throughput_routing) and not args.latency_routing
+        routing = dict(_ops.THROUGHPUT_OPTIONS if thr_routing else _ops.LATENCY_OPTIONS)
         serial_routing = dict(_ops.LATENCY_OPTIONS)
         for kv in args.set_option:
             k_, v_ = kv.split("=")
             routing[k_] = serial_routing[k_] = int(v_)
+        if args.scratch_mb is not None:
+            _ops.SPLITK_WS_BYTES = int(args.scratch_mb) << 20
         from hallo_amd.synthetic import build_pipeline, clip_inputs
         pipe, audioproj = build_pipeline(dev, dtype)
         pipe.routing = routing
@@ -554,15 +566,19 @@ def main():
         serial_pipe = _FAP(vae=pipe.vae, reference_unet=pipe.reference_unet, denoising_unet=pipe.denoising_unet,
                            face_locator=pipe.face_locator, image_proj=pipe.image_proj, scheduler=_mk(), use_graph=pipe.use_graph,
                            routing=serial_routing)
+        if args.shared_scratch:
+            for p_ in pipes[1:]:
+                p_._scratch = pipes[0].scratch
         streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(len(pipes) - 1)]
     from hallo_amd.animate.clip_parallel import gather_wave
     gather_u8 = world > 1 and (args.gather or ("f32" if dry else "u8")) == "u8"
     # rank 0 receives the whole wave (one clip per rank) and copies ALL of it to the host
     n_slots = 1 if dry else len(pipes)
+    KB = 1 if dry else max(1, args.batch_clips)          # clips per group (one UNet evaluation covers a group)
     if gather_u8:
-        hosts = [torch.empty((world if rank == 0 else 1, Fr, S * S, 3), dtype=torch.uint8) for _ in range(n_slots)]
+        hosts = [torch.empty((world if rank == 0 else 1, KB * Fr, S * S, 3), dtype=torch.uint8) for _ in range(n_slots)]
     else:
-        hosts = [torch.empty((world if rank == 0 else 1, Fr, 3, S * S), dtype=torch.float32) for _ in range(n_slots)]
+        hosts = [torch.empty((world if rank == 0 else 1, KB * Fr, 3, S * S), dtype=torch.float32) for _ in range(n_slots)]
     if not dry:
         hosts = [h_.pin_memory() for h_ in hosts]
     host = hosts[0]
@@ -584,7 +600,8 @@ def main():
     # (50 MB read, ~15 us of an 800 ms clip) and compared AFTER the timed region with the same clips run alone
     chk = None if dry else torch.zeros((max(args.steps, 1),), device=dev, dtype=torch.int64)
 
-    def run(d, exchange=True, slot=0, chk_out=None):
+    def run(grp, exchange=True, slot=0, chk_out=None):
+        """grp: list of the clips of one group (one clip unless --batch-clips); chk_out: int64 [len(grp)] checksums out."""
         if not dry and len(pipes) > 1:
             if slot_done[slot] is not None and not args.no_slot_wait:
                 c0 = time.thread_time()
@@ -598,25 +615,36 @@ def main():
                         time.sleep(0.001)
                 wait_cpu[0] += time.thread_time() - c0        # CPU the launch thread spends inside the wait
             with torch.cuda.stream(streams[slot]):
-                r_ = run_on(d, exchange, pipes[slot], hosts[slot], chk_out)
+                r_ = run_on(grp, exchange, pipes[slot], hosts[slot], chk_out)
                 if slot_done[slot] is None:
                     slot_done[slot] = torch.cuda.Event(blocking=True)
                 slot_done[slot].record(streams[slot])
                 return r_
-        return run_on(d, exchange, None if dry else pipes[slot], hosts[slot], chk_out)
+        return run_on(grp, exchange, None if dry else pipes[slot], hosts[slot], chk_out)
 
-    def run_on(d, exchange, pipe, host, chk_out=None):
+    def run_on(grp, exchange, pipe, host, chk_out=None):
+        kb = len(grp)
         if dry:
-            frames = torch.full((Fr, 3, S * S), d["stub"])
+            frames = torch.full((Fr, 3, S * S), grp[0]["stub"])
         else:
-            audio = audioproj(d["audio_emb"])
-            lat = pipe(d["ref_image"], d["face_emb"], audio, d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr,
-                       args.ddim_steps, args.guidance, motion_scale=d["motion_scale"], latents=d["latents"], decode=False)
             h = S // 8
-            lat = lat[0].permute(1, 2, 3, 0).reshape(Fr * h * h, 4).contiguous()
-            frames, _, _ = pipe.decode_latents_device(lat, Fr, h, h)
-            if chk_out is not None:
-                torch.sum(frames.view(torch.int32).view(-1), dim=(0,), keepdim=True, dtype=torch.int64, out=chk_out)
+            if kb == 1:
+                d = grp[0]
+                lats = [pipe(d["ref_image"], d["face_emb"], audioproj(d["audio_emb"]), d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr,
+                             args.ddim_steps, args.guidance, motion_scale=d["motion_scale"], latents=d["latents"], decode=False)]
+            else:
+                clips = [dict(ref_image=d["ref_image"], face_emb=d["face_emb"], audio_tensor=audioproj(d["audio_emb"]), face_mask=d["face_mask"],
+                              pixel_values_full_mask=d["full"], pixel_values_face_mask=d["face"], pixel_values_lip_mask=d["lip"],
+                              latents=d["latents"]) for d in grp]
+                lats = pipe.call_batch(clips, S, S, Fr, args.ddim_steps, args.guidance, motion_scale=grp[0]["motion_scale"], decode=False)
+            fr_ = []
+            for j, lat in enumerate(lats):
+                lat = lat[0].permute(1, 2, 3, 0).reshape(Fr * h * h, 4).contiguous()
+                f_, _, _ = pipe.decode_latents_device(lat, Fr, h, h)
+                if chk_out is not None:
+                    torch.sum(f_.view(torch.int32).view(-1), dim=(0,), keepdim=True, dtype=torch.int64, out=chk_out[j:j + 1])
+                fr_.append(f_)
+            frames = fr_[0] if kb == 1 else torch.cat(fr_)                      # [kb * F, 3, H*W]
         if world > 1 and exchange:
             if gather_u8:      # the video bytes, converted on the device: 4x fewer bytes over xGMI and PCIe
                 send = (frames.clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 1).contiguous() if dry else _ops.frames_to_uint8(frames)
@@ -624,19 +652,29 @@ def main():
                 send = frames
             g = gather_wave(send)                              # RCCL all-gather of decoded frames, clip order = rank
             if rank == 0:
-                host.copy_(g, non_blocking=True)
+                host[:, :g.shape[1]].copy_(g, non_blocking=True)
         elif not gather_u8:
-            host[0].copy_(frames, non_blocking=True)
+            host[0, :frames.shape[0]].copy_(frames, non_blocking=True)
         return frames
 
     inputs = [one_clip(i) for i in range(args.warmup + args.steps)]
+    timed = inputs[args.warmup:]
+    groups = [timed[i:i + KB] for i in range(0, len(timed), KB)]           # the timed clips, in groups of KB (the last one may be smaller)
     graph_note = None
     if not dry and len(pipes) > 1:
         for st_ in streams[1:]:
             st_.wait_stream(streams[0])              # the synthetic inputs were produced on the default stream
-    for i in range(max(args.warmup, 0 if dry else (len(pipes) if args.warmup > 0 else 0))):
+    # warm-up: at least --warmup clips, and every (pipeline, stream) pair runs one group of every size it will see in the timed
+    # region (it captures one hipGraph per batch size)
+    warm = []
+    n_warm_groups = max((max(args.warmup, 0) + KB - 1) // KB, 0 if dry else (n_slots if args.warmup > 0 else 0))
+    for i in range(n_warm_groups):
+        warm.append((i % n_slots, [inputs[(i * KB + j) % len(inputs)] for j in range(KB)]))
+    if not dry and args.warmup > 0 and groups and len(groups[-1]) != KB:
+        warm.append(((len(groups) - 1) % n_slots, [inputs[j % len(inputs)] for j in range(len(groups[-1]))]))
+    for slot_, grp_ in warm:
         try:
-            run(inputs[i % len(inputs)], slot=i % n_slots)     # every (pipeline, stream) pair captures its graph in the warm-up
+            run(grp_, slot=slot_)
         except Exception as e:          # a failed capture must not cost the measurement: eager launches, and say so
             if dry or not pipe.use_graph:
                 raise
@@ -645,7 +683,7 @@ def main():
                 p_.use_graph = False
                 p_.reset_graphs()
             sync()
-            run(inputs[i % len(inputs)], slot=i % n_slots)
+            run(grp_, slot=slot_)
     if world > 1 and not dry:
         # every rank must take the same launch path: if one rank's capture failed, all go eager
         flag = torch.tensor([0 if pipe.use_graph else 1], device=dev, dtype=torch.int32)
@@ -668,9 +706,9 @@ def main():
     thr0 = time.thread_time()
     wait_cpu[0] = 0.0
     tcpu0 = thread_cpu_times()
-    for i in range(args.steps):
+    for gi, grp_ in enumerate(groups):
         th = time.perf_counter()
-        run(inputs[args.warmup + i], slot=i % n_slots, chk_out=None if dry else chk[i:i + 1])
+        run(grp_, slot=gi % n_slots, chk_out=None if dry else chk[gi * KB:gi * KB + len(grp_)])
         host_s += time.perf_counter() - th      # wall time inside the enqueue calls of a clip: includes the runtime's back-pressure
     cpu_main_s = time.thread_time() - thr0      # CPU time of the launch thread alone
     cpu_wait_s = wait_cpu[0]
@@ -703,9 +741,10 @@ def main():
     out = {
         "metric": "generated frames/sec at 512x512, 16-frame window, 25 DDIM steps",
         "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "clip_latency_ms": elapsed / args.steps * 1e3 * n_slots,
-        "value_is": ("THROUGHPUT of %d independent clips in flight per GPU (ms_per_step = timed wall / clips; one clip's latency = clip_latency_ms); "
-                     "rounds 1-3 reported one clip at a time = one_clip_at_a_time.value" % n_slots) if n_slots > 1 else "one clip at a time",
+        "ms_per_step": elapsed / args.steps * 1e3, "clip_latency_ms": elapsed / args.steps * 1e3 * n_slots * KB,
+        "value_is": ("THROUGHPUT of %d independent clips in flight per GPU (%d pipeline(s) x %d clip(s) per UNet evaluation; ms_per_step = timed wall / clips; "
+                     "one clip's latency = clip_latency_ms); rounds 1-3 reported one clip at a time = one_clip_at_a_time.value"
+                     % (n_slots * KB, n_slots, KB)) if n_slots * KB > 1 else "one clip at a time",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype + ("+fp8proj" if args.fp8_proj else ""), "data": "synthetic (random-init weights of the reference architecture, synthetic clip inputs)",
         "config": {"workload": f"{cfg_name} per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
@@ -721,9 +760,11 @@ def main():
                    "host_cores_per_rank": len(pinned) if pinned else len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                    "host_cpu_quota_cores": cpu_quota_cores(),
                    "options": args.set_option or None,
-                   "kernel_routing": ("dry run" if dry else ("throughput: " if (args.inflight > 1 and not args.latency_routing) else "library defaults: ") + str(routing)),
-                   "clips_in_flight_per_gpu": n_slots,
-                   "warmup_clips_run": max(args.warmup, n_slots if args.warmup > 0 else 0),
+                   "scratch": ("ONE launch scratch shared by all pipelines in flight (racy: timing A/B only)" if args.shared_scratch else "own per pipeline")
+                              + (", split-K slab %d MB" % args.scratch_mb if args.scratch_mb is not None else ""),
+                   "kernel_routing": ("dry run" if dry else ("throughput: " if thr_routing else "library defaults: ") + str(routing)),
+                   "clips_in_flight_per_gpu": n_slots * KB, "pipelines_in_flight_per_gpu": n_slots, "clips_per_unet_evaluation": KB,
+                   "warmup_clips_run": sum(len(g_) for _, g_ in warm),
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (
                        f" + RCCL all-gather of the decoded frames ({'uint8 video bytes' if gather_u8 else 'fp32'})" if world > 1 else "")},
     }
@@ -731,12 +772,15 @@ def main():
     # Identity leg (every rank): the first timed clips again, ALONE (device idle before and after each), same pipeline objects, same
     # routing, same graphs -- their frame checksums must equal the ones the timed clips left behind while three clips overlapped.
     # A race between clips in flight (shared scratch, a constant rebuilt under another clip) fails here, and the line says so.
-    if not dry and n_slots > 1:
-        nchk = min(n_slots, args.steps)
+    if not dry and (n_slots > 1 or KB > 1):
+        ngrp = min(n_slots, len(groups))
+        nchk = sum(len(g_) for g_ in groups[:ngrp])
         alone = torch.zeros((nchk,), device=dev, dtype=torch.int64)
-        for i in range(nchk):
+        o_ = 0
+        for gi in range(ngrp):
             sync()
-            run(inputs[args.warmup + i], exchange=False, slot=0, chk_out=alone[i:i + 1])
+            run(groups[gi], exchange=False, slot=0, chk_out=alone[o_:o_ + len(groups[gi])])
+            o_ += len(groups[gi])
         sync()
         same = bool(torch.equal(alone, chk[:nchk]))
         if world > 1:
@@ -744,21 +788,22 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             same = int(flag.item()) == 0
         out["inflight_identity"] = {"clips_checked_per_rank": nchk, "identical": same,
-                                    "how": "int64 sum of the fp32 frames' bit patterns: timed clip i (three in flight) == the same clip run alone afterwards on slot 0"}
+                                    "how": "int64 sum of the fp32 frames' bit patterns: timed clip i (its group in flight next to the other slots' groups) == "
+                                           "the same group run alone afterwards on slot 0"}
         if not same:
             out["INVALID"] = "frames of clips in flight differ from the same clips run alone: the headline is void"
 
     # Reference leg (rank 0, N = 1): the same clips ONE AT A TIME with the library-default kernel routing -- the execution of rounds
     # 1-3 -- so that the line carries both numbers from one process on one box.  3 clips (+ 1 to capture the graph of that routing).
-    if not dry and rank == 0 and world == 1 and n_slots > 1 and not args.no_serial_leg:
+    if not dry and rank == 0 and world == 1 and (n_slots > 1 or KB > 1) and not args.no_serial_leg:
         try:
             sync()
-            run_on(inputs[0], False, serial_pipe, hosts[0])              # captures the graph of this routing
+            run_on([inputs[0]], False, serial_pipe, hosts[0])            # captures the graph of this routing
             sync()
             ts = time.perf_counter()
             nser = min(3, len(inputs))
             for i in range(nser):
-                run_on(inputs[i], False, serial_pipe, hosts[0])
+                run_on([inputs[i]], False, serial_pipe, hosts[0])
             sync()
             tser = time.perf_counter() - ts
             out["one_clip_at_a_time"] = {"value": nser * Fr / tser, "unit": "frames/s", "clips": nser, "ms_per_clip": tser / nser * 1e3,
@@ -779,12 +824,12 @@ def main():
         out["data"] = "DRY RUN on CPU (control-flow test, the clip is a stub): NOT a measurement"
         out["dry_run_wave"] = [float(v) for v in host[:, 0, 0, 0]] if rank == 0 else None
         if rank == 0:
-            run(inputs[-1], exchange=False)     # the rank-0-only instrumented leg of the real run
+            run([inputs[-1]], exchange=False)   # the rank-0-only instrumented leg of the real run
     elif rank == 0 and not args.no_profile:
         prof = OpProfiler()
         prof.install(dtype)
         pipe.use_graph = False              # the instrumented clip brackets every launch with events: eager
-        run(inputs[-1], exchange=False)     # rank 0 alone: the instrumented clip must not enter a collective
+        run([inputs[-1]], exchange=False)   # rank 0 alone: the instrumented clip must not enter a collective
         fam = prof.summary()
         prof.remove()
         if args.shape_breakdown:

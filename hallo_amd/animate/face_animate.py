@@ -27,7 +27,7 @@ from dataclasses import dataclass
 import torch
 
 from .. import ops
-from ..models.attention import SKIP_BANK, ClipCache
+from ..models.attention import CLIP_BATCH, SKIP_BANK, ClipCache
 from ..models.mutual_self_attention import ReferenceAttentionControl
 from ..models.unet_3d import pack_masks
 from .image_processor import preprocess_image
@@ -162,17 +162,51 @@ class FaceAnimatePipeline:
         with ops.routing(self.routing), ops.scratch_scope(self.scratch):
             return self._call(*args, **kwargs)
 
+    @torch.no_grad()
+    def call_batch(self, clips, width, height, video_length, num_inference_steps, guidance_scale=1.0, **kwargs):
+        """K INDEPENDENT clips through ONE denoising loop: every UNet evaluation runs on the K x video_length frames of all clips
+        (the reference already batches two evaluations for CFG, hallo/animate/face_animate.py:397-417; hallo/models/unet_3d.py:
+        510-527 takes any batch).  Each clip is computed exactly as `__call__` would compute it alone -- its own reference /
+        motion-frame banks (frame row r reads the bank of clip r // video_length, not the reference's CFG tiling r % batch), face
+        tokens, audio tokens, masks, latents -- but the weights are read once for K clips and the 16 x 16 / 8 x 8 levels present
+        K times the rows to the GEMM / convolution tiles (4096 / 1024 rows per clip leave most of a 256-CU chip idle or force a
+        split-K slab + reduce pass).  Independent clips are the shard unit of the path (scripts/inference.py:285-347 with each
+        clip given its reference / motion frames: DESIGN section 8); inside ONE video the clips are sequential and cannot be
+        batched.
+        clips: list of dicts with the per-clip arguments of `__call__` (ref_image, face_emb, audio_tensor, face_mask,
+        pixel_values_full_mask, pixel_values_face_mask, pixel_values_lip_mask, and optionally latents / generator); the other
+        arguments are shared.  No classifier-free guidance (guidance_scale <= 1) when K > 1.
+        Returns a list of K outputs, each what `__call__` returns for that clip (with decode=False: the latents (1, C, F, h, w))."""
+        with ops.routing(self.routing), ops.scratch_scope(self.scratch):
+            return self._call_clips(list(clips), width, height, video_length, num_inference_steps, guidance_scale, **kwargs)
+
     def _call(self, ref_image, face_emb, audio_tensor, face_mask, pixel_values_full_mask, pixel_values_face_mask,
               pixel_values_lip_mask, width, height, video_length, num_inference_steps, guidance_scale,
               num_images_per_prompt=1, eta=0.0, motion_scale=None, generator=None, output_type="tensor",
               return_dict=True, callback=None, callback_steps=1, latents=None, decode=True, **kwargs):
+        clip = dict(ref_image=ref_image, face_emb=face_emb, audio_tensor=audio_tensor, face_mask=face_mask,
+                    pixel_values_full_mask=pixel_values_full_mask, pixel_values_face_mask=pixel_values_face_mask,
+                    pixel_values_lip_mask=pixel_values_lip_mask, generator=generator, latents=latents)
+        return self._call_clips([clip], width, height, video_length, num_inference_steps, guidance_scale, eta=eta,
+                                motion_scale=motion_scale, output_type=output_type, return_dict=return_dict, callback=callback,
+                                callback_steps=callback_steps, decode=decode)[0]
+
+    def _call_clips(self, clips, width, height, video_length, num_inference_steps, guidance_scale, num_images_per_prompt=1,
+                    eta=0.0, motion_scale=None, output_type="tensor", return_dict=True, callback=None, callback_steps=1,
+                    decode=True, **kwargs):
         if eta != 0.0:
             raise ValueError("the Hallo path runs DDIM with eta = 0 (face_animate.py:420)")
+        K = len(clips)
         dev = self.device
         dt = self.denoising_unet.dtype
         den, refnet = self.denoising_unet, self.reference_unet
         do_cfg = guidance_scale > 1.0
-        B = 2 if do_cfg else 1
+        if K < 1 or (K > 1 and do_cfg):
+            raise ValueError("call_batch: K >= 1 clips, and no classifier-free guidance for K > 1 (the reference tiles the "
+                             "banks of a CFG pair over the batch axis, mutual_self_attention.py:235-247: a batch of CFG pairs "
+                             "has no single bank map)")
+        B = 2 if do_cfg else K                     # batch entries of one UNet evaluation
+        mode = CLIP_BATCH if K > 1 else do_cfg     # the bank rule of the spatial self-attention (models/attention.py)
         Fr = video_length
         h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
         L = h * w
@@ -180,6 +214,7 @@ class FaceAnimatePipeline:
         timesteps = self.scheduler.timesteps
 
         # -- face tokens (face_animate.py:291-298)
+        face_emb = clips[0]["face_emb"] if K == 1 else torch.cat([c["face_emb"].reshape(-1, c["face_emb"].shape[-1]) for c in clips])
         cond = self.image_proj(face_emb)
         if do_cfg:
             enc = torch.cat([self.image_proj(torch.zeros_like(face_emb)), cond], dim=0)
@@ -191,13 +226,14 @@ class FaceAnimatePipeline:
         reader = ReferenceAttentionControl(den, do_classifier_free_guidance=do_cfg, mode="read", batch_size=1,
                                            fusion_blocks="full")
 
-        # -- latents: fp32 token-major state [F*L, C] + the UNet input buffer [B*F, L, 8]
+        # -- latents: fp32 token-major state [K*F*L, C] + the UNet input buffer [B*F, L, 8]
         C_lat = den.in_channels
-        lat5 = self.prepare_latents(1, C_lat, width, height, Fr, dt, dev, generator, latents)
-        lat = lat5[0].permute(1, 2, 3, 0).reshape(Fr * L, C_lat).float().contiguous()
+        lat = torch.cat([self.prepare_latents(1, C_lat, width, height, Fr, dt, dev, c.get("generator"), c.get("latents"))[0]
+                         .permute(1, 2, 3, 0).reshape(Fr * L, C_lat).float() for c in clips]).contiguous()
         C0 = den.config.block_out_channels[0]
         split = bool(do_cfg and self.cfg_split)
         sg = None
+        ref0, audio0 = clips[0]["ref_image"], clips[0]["audio_tensor"]
         if self.use_graph:
             # prepare() is lazy: after den.load_state_dict() / den.to() the weight images (and prepare_epoch) of the NEXT forward
             # differ from what the attribute says now.  Re-prepare here, so that the epoch in the key is the one step 0 runs
@@ -205,8 +241,8 @@ class FaceAnimatePipeline:
             den.prepare()
             refnet.prepare()
             ms_key = None if motion_scale is None else tuple(float(m) for m in motion_scale)
-            key = (B, Fr, h, w, dt, str(dev), ref_image.shape[1] if ref_image.dim() == 5 else ref_image.shape[0], ms_key,
-                   tuple(audio_tensor.shape[-2:]), tuple(enc.shape[1:]), ops.options_fingerprint(),
+            key = (B, K, Fr, h, w, dt, str(dev), ref0.shape[1] if ref0.dim() == 5 else ref0.shape[0], ms_key,
+                   tuple(audio0.shape[-2:]), tuple(enc.shape[1:]), ops.options_fingerprint(),
                    bool(getattr(den, "fp8_projections", False)), bool(do_cfg and self.cfg_split), den.prepare_epoch)
             sg = self._graphs.get(key)
             if sg is None:
@@ -218,29 +254,44 @@ class FaceAnimatePipeline:
                     del self._graphs[next(iter(self._graphs))]
                 sg = self._graphs[key] = StepGraph(B, Fr, L, C0, dev, dt, split=split, out_channels=den.conv_out.cout)
         x_in = sg.x_in if sg is not None else torch.zeros((B * Fr, L, 8), device=dev, dtype=dt)
-        x_in.view(B, Fr * L, 8)[:, :, :C_lat] = lat.to(dt)
+        if do_cfg:
+            x_in.view(B, Fr * L, 8)[:, :, :C_lat] = lat.to(dt)
+        else:
+            x_in.view(K * Fr * L, 8)[:, :C_lat] = lat.to(dt)
 
-        # -- reference + motion frames -> latents (face_animate.py:332-336)
-        imgs = ref_image.reshape(-1, *ref_image.shape[2:]) if ref_image.dim() == 5 else ref_image
-        imgs = preprocess_image(imgs, height, width, normalize=True)                # ref_image_processor.preprocess (:119-121, 333)
+        # -- reference + motion frames -> latents (face_animate.py:332-336); per clip: the processor's normalisation rule looks at
+        # the whole tensor it is given
+        def ref_tokens(r):
+            imgs = r.reshape(-1, *r.shape[2:]) if r.dim() == 5 else r
+            return preprocess_image(imgs, height, width, normalize=True)          # ref_image_processor.preprocess (:119-121, 333)
+        imgs = torch.cat([ref_tokens(c["ref_image"]) for c in clips])
         n_ref = imgs.shape[0]
+        per_clip = n_ref // K                                                       # 1 reference + n motion frames
         ref_lat, _, _ = self.vae.encode_tokens(self._image_tokens(imgs, dt), n_ref, height, width, scale=0.18215)
 
-        # -- face locator on one frame, broadcast over the F identical frames (face_animate.py:339-343)
-        fm = self._image_tokens(face_mask.reshape(-1, *face_mask.shape[-3:])[:1], dt)
-        fea, _, _ = self.face_locator.forward_tokens(fm, 1, height, width)          # [1, L, C0]
+        # -- face locator on one frame per clip, broadcast over the F identical frames (face_animate.py:339-343)
+        fm = self._image_tokens(torch.cat([c["face_mask"].reshape(-1, *c["face_mask"].shape[-3:])[:1] for c in clips]), dt)
+        fea, _, _ = self.face_locator.forward_tokens(fm, K, height, width)          # [K, L, C0]
         assert fea.shape[-1] == C0
         mask_cond = sg.mask_cond.view(B, Fr, L, C0) if sg is not None else torch.zeros((B, Fr, L, C0), device=dev, dtype=dt)
-        mask_cond[B - 1] = fea[0]                                                   # uncond half stays zero
+        if do_cfg:
+            mask_cond[B - 1] = fea[0]                                               # uncond half stays zero
+        else:
+            mask_cond[:] = fea[:, None]
         mask_cond = mask_cond.view(B * Fr, L, C0)
 
         # -- masks (face_animate.py:345-374) and audio tokens (:377-379)
-        rep = (lambda ms: [torch.cat([m] * 2) for m in ms]) if do_cfg else (lambda ms: list(ms))
-        masks = pack_masks(rep(pixel_values_full_mask), rep(pixel_values_face_mask), rep(pixel_values_lip_mask), dev, dt)
-        audio = audio_tensor.to(dev, dt)
+        def mask_rows(name):
+            per = [c[name] for c in clips]
+            if do_cfg:
+                return [torch.cat([m] * 2) for m in per[0]]
+            return list(per[0]) if K == 1 else [torch.cat([p_[d] for p_ in per]) for d in range(len(per[0]))]
+        masks = pack_masks(mask_rows("pixel_values_full_mask"), mask_rows("pixel_values_face_mask"),
+                           mask_rows("pixel_values_lip_mask"), dev, dt)
+        audio = torch.cat([c["audio_tensor"].to(dev, dt).reshape(Fr, *c["audio_tensor"].shape[-2:]) for c in clips])
         if do_cfg:
             audio = torch.cat([torch.zeros_like(audio), audio], dim=0)
-        audio = audio.reshape(B * Fr, audio.shape[-2], audio.shape[-1]).contiguous()
+        audio = audio.contiguous()
 
         if split:
             halves = sg.halves if sg is not None else [StepGraph(1, 0, L, 8, dev, dt) for _ in range(2)]
@@ -253,10 +304,16 @@ class FaceAnimatePipeline:
             cache.begin_clip()          # step 0 (eager) refreshes the per-clip constants inside their old storage
         else:
             cache = ClipCache()
+        lat_view = lambda: lat.view(K, Fr, h, w, C_lat).permute(0, 4, 1, 2, 3)        # (K, C, F, h, w)
         for i, t in enumerate(self.progress_bar(timesteps)):
             if i == 0:
-                # ReferenceNet write pass on [ref, m1, m2] (x2 under CFG) at t = 0 (face_animate.py:386-395)
-                refnet.written_banks = refnet.forward_tokens(ref_lat.repeat(B, 1, 1), 0, enc, h, w)
+                # ReferenceNet write pass on [ref, m1, m2] (x2 under CFG) at t = 0 (face_animate.py:386-395).  K > 1: the images
+                # of clip c attend to clip c's face tokens (the reference TILES enc over the image axis, which is only defined
+                # for a CFG pair: mutual_self_attention.py:341-349)
+                if K > 1:
+                    refnet.written_banks = refnet.forward_tokens(ref_lat, 0, enc.repeat_interleave(per_clip, 0), h, w)
+                else:
+                    refnet.written_banks = refnet.forward_tokens(ref_lat.repeat(B, 1, 1), 0, enc, h, w)
                 reader.update(writer)
             if split:
                 v = self._split_eval(halves, sg is not None and i > 0, t, x_in, v_out, enc, den.reference_bank, audio, mask_cond,
@@ -267,33 +324,36 @@ class FaceAnimatePipeline:
                 sg.t_dev.fill_(float(t))
                 if sg.graph is None:
                     sg.capture(lambda: den.forward_tokens(x_in, sg.t_dev, enc, den.reference_bank, audio, mask_cond, masks,
-                                                          motion_scale, B, Fr, h, w, do_cfg, cache))
+                                                          motion_scale, B, Fr, h, w, mode, cache))
                 sg.graph.replay()
                 sg.replays += 1
                 v = sg.out
             else:
                 v = den.forward_tokens(x_in, int(t), enc, den.reference_bank, audio, mask_cond, masks, motion_scale, B, Fr,
-                                       h, w, do_cfg, cache)
+                                       h, w, mode, cache)
             a_t, a_p = self.scheduler.step_alphas(t)
-            ops.cfg_ddim_step(v, lat, x_in, Fr * L, C_lat, do_cfg, guidance_scale, a_t, a_p, self.scheduler.step_mode)
+            ops.cfg_ddim_step(v, lat, x_in, K * Fr * L, C_lat, do_cfg, guidance_scale, a_t, a_p, self.scheduler.step_mode)
             if callback is not None and i % callback_steps == 0:
-                callback(i, t, lat.view(Fr, h, w, C_lat).permute(3, 0, 1, 2).unsqueeze(0).to(dt))
+                callback(i, t, lat_view().to(dt))
         reader.clear()
         writer.clear()
         if sg is None and cache is not None:
             cache.clear()
-        if not decode:
-            return lat.view(Fr, h, w, C_lat).permute(3, 0, 1, 2).unsqueeze(0)
-        if output_type == "device":
-            # frames stay in HBM ((1, 3, F, H, W) fp32): the sliding-window driver slices the next clip's motion frames
-            # from them and converts / copies asynchronously (hallo_amd/animate/video.py)
-            v, H, W = self.decode_latents_device(lat, Fr, h, w)
-            video = v.view(Fr, -1, H, W).permute(1, 0, 2, 3).unsqueeze(0)
-        else:
-            video = self.decode_latents(lat, Fr, h, w)
-        if not return_dict:
-            return video
-        return FaceAnimatePipelineOutput(videos=video)
+        outs = []
+        for c in range(K):
+            lat_c = lat[c * Fr * L:(c + 1) * Fr * L]
+            if not decode:
+                outs.append(lat_c.view(Fr, h, w, C_lat).permute(3, 0, 1, 2).unsqueeze(0))
+                continue
+            if output_type == "device":
+                # frames stay in HBM ((1, 3, F, H, W) fp32): the sliding-window driver slices the next clip's motion frames
+                # from them and converts / copies asynchronously (hallo_amd/animate/video.py)
+                v, H, W = self.decode_latents_device(lat_c, Fr, h, w)
+                video = v.view(Fr, -1, H, W).permute(1, 0, 2, 3).unsqueeze(0)
+            else:
+                video = self.decode_latents(lat_c, Fr, h, w)
+            outs.append(video if not return_dict else FaceAnimatePipelineOutput(videos=video))
+        return outs
 
     def _split_eval(self, halves, graphed, t, x_in, v_out, enc, banks, audio, mask_cond, masks, motion_scale, Fr, h, w):
         """One CFG evaluation as two B = 1 evaluations: uncond (rows 0..Fr of every [2 Fr, ...] tensor, bank rows 0..2, no bank

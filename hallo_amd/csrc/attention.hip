@@ -432,6 +432,14 @@ static int launch_attn(const AttnArgs& a, int hd, bool pre, hipStream_t st) {
   return 0;
 }
 
+// Frame row of temporal position f (0 <= f < F) of batch entry b in the [frames, HW, C] tensors of hallo_temporal_attention_lead:
+// the first `lead` positions of every batch entry (the motion frames put in front of a clip, unet_3d_blocks.py:696-748) are
+// stored together at the FRONT -- rows [b * lead, (b + 1) * lead) -- and the other F - lead positions of entry b behind all of
+// them, so that the clip rows of every batch entry form one contiguous [B * (F - lead), HW, C] block.  lead = 0: rows b * F + f.
+__device__ __forceinline__ long temporal_frame_row(long b, int f, int F, int lead, int B) {
+  return f < lead ? b * lead + f : (long)B * lead + b * (F - lead) + (f - lead);
+}
+
 // -------------------------------------------------------------------------------------------
 // Temporal (per-pixel, over frames) attention.  One workgroup = one pixel of one batch entry and
 // a group of HPB heads; the F' x 3 x (HPB*hd) slab [q|k|v] of that pixel is staged in LDS with
@@ -442,7 +450,7 @@ static int launch_attn(const AttnArgs& a, int hd, bool pre, hipStream_t st) {
 template <typename T>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                             int F, int HW, int C, int hd, int hpb,
-                                                            float scale_log2e) {
+                                                            float scale_log2e, int lead, int B) {
   using V8 = typename Vec<T>::v8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int Wd = hpb * hd;                    // channels handled by this block
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
       if (u < total) {
         const int f = u / (3 * vpp), rem = u - f * 3 * vpp;
         const int part = rem / vpp, v = rem - part * vpp;
-        const long row = ((long)(b * F + f) * HW + pix);
+        const long row = (temporal_frame_row(b, f, F, lead, B) * HW + pix);
         tmp[i] = ld8<T>(qkv + row * C3 + (long)part * C + cbase + v * 8);
         dst[i] = f * W3 + part * Wd + v * 8;
       }
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
     for (int u = tid + 256 * MAXU; u < total; u += 256) {     // not reached for F <= 32 with <= 160 channels per block
       const int f = u / (3 * vpp), rem = u - f * 3 * vpp;
       const int part = rem / vpp, v = rem - part * vpp;
-      const long row = ((long)(b * F + f) * HW + pix);
+      const long row = (temporal_frame_row(b, f, F, lead, B) * HW + pix);
       st8<T>(&sQKV[f * W3 + part * Wd + v * 8], ld8<T>(qkv + row * C3 + (long)part * C + cbase + v * 8));
     }
   }
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
     V8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(acc[e]);
-    const long row = ((long)(b * F + i) * HW + pix);
+    const long row = (temporal_frame_row(b, i, F, lead, B) * HW + pix);
     st8<T>(out + row * C + cbase + c0, o);
   }
 }
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
 // -------------------------------------------------------------------------------------------
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                                 int F, int HW, int C, int heads, float scale_log2e) {
+                                                                 int F, int HW, int C, int heads, float scale_log2e, int lead, int B) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   constexpr int HDP = ((HD + 15) / 16) * 16;
@@ -564,12 +572,11 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const T* __rest
   const long b = bp / HW;
   const int h = hg * 4 + wave;
   const long C3 = 3L * C;
-  const long fstride = (long)HW * C3;                 // elements between consecutive frames of one pixel
-  const T* base = qkv + ((b * F) * (long)HW + pix) * C3 + (long)h * HD;
   const int fr = min(l31, F - 1);                     // rows >= F re-read the last frame (valid memory), masked below
+  const long frow = temporal_frame_row(b, fr, F, lead, B);   // this lane's frame row of the [frames, HW, .] tensors
 
   // ---- S^T = K . Q^T ----
-  const T* qrow = base + fr * fstride;
+  const T* qrow = qkv + (frow * HW + pix) * C3 + (long)h * HD;
   const T* krow = qrow + C;
   V8 qf[NKS], kf[NKS];
 #pragma unroll
@@ -625,7 +632,7 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const T* __rest
 
   // ---- O^T = V^T . P^T, normalise, store rows i < F (lane = query frame, 8-byte stores) ----
   const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  T* orow = out + ((b * F + fr) * (long)HW + pix) * C + (long)h * HD;
+  T* orow = out + (frow * HW + pix) * C + (long)h * HD;
   // the tile is private to the wave: LDS operations of one wave complete in order, no barrier
   typedef __attribute__((ext_vector_type(4))) short s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -670,7 +677,7 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const T* __rest
 // -------------------------------------------------------------------------------------------
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void temporal_attn_tiled_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                                  int F, int HW, float scale_log2e) {
+                                                                  int F, int HW, float scale_log2e, int lead, int B) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   constexpr int HEADS = 8, C = HEADS * HD, C3 = 3 * C;
@@ -689,8 +696,8 @@ __global__ __launch_bounds__(256) void temporal_attn_tiled_kernel(const T* __res
   const long bp = xcd_remap((int)blockIdx.x, (int)gridDim.x);       // b * HW + pixel
   const int pix = (int)(bp % HW);
   const long b = bp / HW;
-  const long fstride = (long)HW * C3;
-  const T* base = qkv + ((b * F) * (long)HW + pix) * C3;
+  // element offset of temporal position f's row of this pixel (two row segments: temporal_frame_row)
+  auto frame_off = [&](int f) { return (temporal_frame_row(b, f, F, lead, B) * HW + pix) * (long)C3; };
 
   // ---- the F rows of this pixel -> LDS ----
   {
@@ -699,7 +706,7 @@ __global__ __launch_bounds__(256) void temporal_attn_tiled_kernel(const T* __res
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) {
       const int u = tid + 256 * i;
-      if (u < total) { const int f = u / CPR, cc = u - f * CPR; tmp[i] = ld8<T>(base + f * fstride + cc * 8); }
+      if (u < total) { const int f = u / CPR, cc = u - f * CPR; tmp[i] = ld8<T>(qkv + frame_off(f) + cc * 8); }
     }
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) {
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(256) void temporal_attn_tiled_kernel(const T* __res
     }
     for (int u = tid + 256 * MAXU; u < total; u += 256) {
       const int f = u / CPR, cc = u - f * CPR;
-      *reinterpret_cast<V8*>(tile + f * PITCH + cc * 16) = ld8<T>(base + f * fstride + cc * 8);
+      *reinterpret_cast<V8*>(tile + f * PITCH + cc * 16) = ld8<T>(qkv + frame_off(f) + cc * 8);
     }
   }
   __syncthreads();
@@ -778,7 +785,7 @@ __global__ __launch_bounds__(256) void temporal_attn_tiled_kernel(const T* __res
   // ---- the C output elements of every frame leave as whole lines ----
   for (int u = tid; u < F * OPR; u += 256) {
     const int f = u / OPR, cc = u - f * OPR;
-    st8<T>(out + ((b * F + f) * (long)HW + pix) * C + cc * 8, *reinterpret_cast<const V8*>(tile + f * PITCH + cc * 16));
+    st8<T>(out + (temporal_frame_row(b, f, F, lead, B) * HW + pix) * C + cc * 8, *reinterpret_cast<const V8*>(tile + f * PITCH + cc * 16));
   }
 }
 
@@ -1052,9 +1059,17 @@ extern "C" int hallo_set_option_attn(const char* name, int value) {
   return -22;
 }
 
+extern "C" int hallo_temporal_attention_lead(const void* qkv, void* out, int B, int F, int lead, int HW, int C, int heads,
+                                             float scale, int dtype, void* stream);
+
 extern "C" int hallo_temporal_attention(const void* qkv, void* out, int B, int F, int HW, int C, int heads,
                                         float scale, int dtype, void* stream) {
-  if (!qkv || !out || B <= 0 || F <= 0 || F > 32 || HW <= 0 || C <= 0 || heads <= 0) return -22;
+  return hallo_temporal_attention_lead(qkv, out, B, F, 0, HW, C, heads, scale, dtype, stream);
+}
+
+extern "C" int hallo_temporal_attention_lead(const void* qkv, void* out, int B, int F, int lead, int HW, int C, int heads,
+                                             float scale, int dtype, void* stream) {
+  if (!qkv || !out || B <= 0 || F <= 0 || F > 32 || HW <= 0 || C <= 0 || heads <= 0 || lead < 0 || lead >= F) return -22;
   if (C % heads || (C / heads) % 8) return -22;
   const int hd = C / heads;
   hipStream_t st0 = reinterpret_cast<hipStream_t>(stream);
@@ -1074,7 +1089,7 @@ extern "C" int hallo_temporal_attention(const void* qkv, void* out, int B, int F
         attr_done[dev][slot] = true;                                                                                                           \
       }                                                                                                                                        \
       hipLaunchKernelGGL((temporal_attn_tiled_kernel<TT, HDv>), dim3((unsigned)((long)B * HW)), dim3(256), lds, st0,                            \
-                         reinterpret_cast<const TT*>(qkv), reinterpret_cast<TT*>(out), F, HW, sl0);                                            \
+                         reinterpret_cast<const TT*>(qkv), reinterpret_cast<TT*>(out), F, HW, sl0, lead, B);                                            \
     } while (0)
     if (dtype == DT_F16) { if (hd == 40) HALLO_TTILED(_Float16, 40); else HALLO_TTILED(_Float16, 80); }
     else { if (hd == 40) HALLO_TTILED(__bf16, 40); else HALLO_TTILED(__bf16, 80); }
@@ -1086,7 +1101,7 @@ extern "C" int hallo_temporal_attention(const void* qkv, void* out, int B, int F
     const float sl0 = scale * 1.4426950408889634f;
     dim3 grid((unsigned)((long)B * HW * (heads / 4))), block(256);
 #define HALLO_TMFMA(TT, HDv) hipLaunchKernelGGL((temporal_attn_mfma_kernel<TT, HDv>), grid, block, 0, st0, \
-    reinterpret_cast<const TT*>(qkv), reinterpret_cast<TT*>(out), F, HW, C, heads, sl0)
+    reinterpret_cast<const TT*>(qkv), reinterpret_cast<TT*>(out), F, HW, C, heads, sl0, lead, B)
     if (dtype == DT_F16) { if (hd == 40) HALLO_TMFMA(_Float16, 40); else if (hd == 80) HALLO_TMFMA(_Float16, 80); else HALLO_TMFMA(_Float16, 160); }
     else { if (hd == 40) HALLO_TMFMA(__bf16, 40); else if (hd == 80) HALLO_TMFMA(__bf16, 80); else HALLO_TMFMA(__bf16, 160); }
 #undef HALLO_TMFMA
@@ -1104,10 +1119,10 @@ extern "C" int hallo_temporal_attention(const void* qkv, void* out, int B, int F
   const float sl = scale * 1.4426950408889634f;
   if (dtype == DT_F16) {
     hipLaunchKernelGGL((temporal_attn_kernel<_Float16>), grid, block, lds, st,
-                       reinterpret_cast<const _Float16*>(qkv), reinterpret_cast<_Float16*>(out), F, HW, C, hd, hpb, sl);
+                       reinterpret_cast<const _Float16*>(qkv), reinterpret_cast<_Float16*>(out), F, HW, C, hd, hpb, sl, lead, B);
   } else if (dtype == DT_BF16) {
     hipLaunchKernelGGL((temporal_attn_kernel<__bf16>), grid, block, lds, st,
-                       reinterpret_cast<const __bf16*>(qkv), reinterpret_cast<__bf16*>(out), F, HW, C, hd, hpb, sl);
+                       reinterpret_cast<const __bf16*>(qkv), reinterpret_cast<__bf16*>(out), F, HW, C, hd, hpb, sl, lead, B);
   } else {
     return -22;
   }

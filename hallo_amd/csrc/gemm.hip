@@ -699,8 +699,13 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (MODE == 1 || MODE == 3 || E
         if (p.splits > 1) {
           if (m < p.M && n < p.N) {
             float* sp = p.slab + ((long)blockIdx.y * p.M + m) * p.N + n;
-            *reinterpret_cast<f32x4*>(sp) = v0;
-            *reinterpret_cast<f32x4*>(sp + 4) = v1;
+            if (p.slab_nt) {
+              __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(sp));
+              __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(sp + 4));
+            } else {
+              *reinterpret_cast<f32x4*>(sp) = v0;
+              *reinterpret_cast<f32x4*>(sp + 4) = v1;
+            }
           }
         } else if (m < p.M && n < p.N) {
           float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -782,7 +787,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int sidx = 0; sidx < p.splits; ++sidx) {
     const float* sp = p.slab + ((long)sidx * p.M + m) * p.N + n;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+    f32x4 a, b;
+    if (p.slab_nt >= 2) {
+      a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp));
+      b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + 4));
+    } else {
+      a = *reinterpret_cast<const f32x4*>(sp); b = *reinterpret_cast<const f32x4*>(sp + 4);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { o[j] += a[j]; o[4 + j] += b[j]; }
   }
@@ -864,6 +875,7 @@ static int g_v3_min_tiles = 192; // auto: smallest grid (workgroups, 1 per CU) w
 // 1000 * LNF (gemm2: 0 none, 1 in-loop LayerNorm statistics, 2 external) + 100 * kernel (1 gemm_kernel, 2 gemm2_kernel,
 // 3 gemm3_kernel) + 10 * mode (0 gemm, 1 conv, 2 geglu) + stages / TM (+ 4 for the persistent gemm3 mode)
 static int g_last_kernel = 0;
+static int g_splitk_nt = 0;      // hallo_set_option("splitk_nt", 0 | 1 | 2): non-temporal split-K slab stores (+ loads): A/B of the slab's cache footprint with several clips in flight
 static int g_split_max = 16;         // hallo_set_option("split_k_max", n): cap of the split-K factor (slab traffic grows with it; under concurrency fewer, longer workgroups cost less than they do alone)
 static int g_stage_min_tiles = 640;  // hallo_set_option("gemm_stage_min_tiles", n): grids of >= n tiles take the 1-stage 128x128 kernel (4 workgroups per CU), smaller ones the 2-stage form
 static int g_gemm4_min_nk = 40;  // hallo_set_option("gemm4_min_nk", n): shortest K loop (64-deep steps) the auto rule gives to gemm4.hip (A/B)
@@ -878,7 +890,7 @@ static int g_row_parts = 1;      // hallo_set_option("row_parts", 0 | 1 | 2): 0 
 template <typename T>
 static int launch_gemm_impl(GemmArgs a, bool conv, bool geglu, int batch, void* ws, int64_t ws_bytes, hipStream_t st, bool* emitted) {
   const int nk = (a.K + BK - 1) / BK;
-  a.splits = 1; a.nk_per_split = 0; a.slab = nullptr;
+  a.splits = 1; a.nk_per_split = 0; a.slab = nullptr; a.slab_nt = g_splitk_nt;
   int v = a.vec_ok ? g_gemm_variant : 0;
   const bool lnf = a.ln_colsum != nullptr;      // fused LayerNorm: 128x128 LDS-DMA kernel only, no split-K
   const bool gelu = a.act >= ACT_GELU;          // GELU epilogues (wav2vec2 front-end): own instantiation of the 128x128 kernel
@@ -1214,6 +1226,7 @@ extern "C" int hallo_get_option(const char* name) {
   if (!strcmp(name, "gemm4_min_nk")) return g_gemm4_min_nk;
   if (!strcmp(name, "gemm_stage_min_tiles")) return g_stage_min_tiles;
   if (!strcmp(name, "split_k_max")) return g_split_max;
+  if (!strcmp(name, "splitk_nt")) return g_splitk_nt;
   if (!strcmp(name, "gemm_rs")) return g_gemm_rs;
   if (!strcmp(name, "gemm_rs_dbg")) return g_rs_dbg_value;
   if (!strcmp(name, "ff_fused")) return ff_fused_variant();
@@ -1236,6 +1249,7 @@ extern "C" int hallo_set_option(const char* name, int value) {
   if (!strcmp(name, "gemm4_min_nk")) { if (value < 4) return -22; g_gemm4_min_nk = value; return 0; }
   if (!strcmp(name, "gemm_stage_min_tiles")) { if (value < 0) return -22; g_stage_min_tiles = value; return 0; }
   if (!strcmp(name, "split_k_max")) { if (value < 1) return -22; g_split_max = value; return 0; }
+  if (!strcmp(name, "splitk_nt")) { if (value < 0 || value > 2) return -22; g_splitk_nt = value; return 0; }
   if (!strcmp(name, "ff_fused")) {          // 0 / 1; 2.. = A/B and timing-ablation forms of a -DHALLO_ABLATIONS build
 #ifdef HALLO_ABLATIONS
     if (value < 0 || value > 9) return -22;

@@ -439,8 +439,13 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
         if (!(n_ok && m < p.M)) continue;
         if (p.splits > 1) {
           float* sp = p.slab + ((long)blockIdx.y * p.M + m) * p.N + n;
-          *reinterpret_cast<f32x4*>(sp) = v0;
-          *reinterpret_cast<f32x4*>(sp + 4) = v1;
+          if (p.slab_nt) {
+            __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(sp));
+            __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(sp + 4));
+          } else {
+            *reinterpret_cast<f32x4*>(sp) = v0;
+            *reinterpret_cast<f32x4*>(sp + 4) = v1;
+          }
           continue;
         }
         float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};

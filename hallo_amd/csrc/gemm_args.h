@@ -32,6 +32,7 @@ struct GemmArgs {
   int tiles_n, tiles_m;
   int splits, nk_per_split;   // split-K: blockIdx.y = split, each split owns nk_per_split K tiles
   float* slab;                // fp32 partial sums [splits][M][N] (splits > 1)
+  int slab_nt;                // hallo_set_option("splitk_nt"): 1 = non-temporal slab stores, 2 = + non-temporal loads in the reduce pass (A/B)
   int vec_ok, res_vec_ok, bias_vec_ok, bias2_vec_ok;   // 8-byte (fp32: 16-byte) row accesses are aligned
   // conv gather
   int H, W, Cin, OH, OW, stride, pad_t, pad_l, upsample;

@@ -113,6 +113,8 @@ SYMBOLS = {
     "hallo_attention": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
     "hallo_temporal_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_float, C.c_int, C.c_void_p]),
+    "hallo_temporal_attention_lead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_float, C.c_int, C.c_void_p]),
     "hallo_groupnorm_chunks": (C.c_int, [C.c_int]),
     "hallo_groupnorm_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),

@@ -83,6 +83,7 @@ class _NoCache:
 
 NO_CACHE = _NoCache()
 SKIP_BANK = "skip_bank"      # `do_cfg` value of a B = 1 evaluation of the UNCOND half of a CFG pair: no row reads the reference bank
+CLIP_BATCH = "clip_batch"    # `do_cfg` value of a batch of INDEPENDENT clips without CFG: frame row r reads the bank of clip r // frames
 
 
 class BasicTransformerBlock(nn.Module):
@@ -142,13 +143,20 @@ class TemporalBasicTransformerBlock(nn.Module):
         fp16-rounded: ReferenceAttentionControl.update casts to fp16 whatever the run dtype, :404,452).
         bank_layout = (bank batches bb, this call's first batch, its first global frame row row0): the call evaluates a SLICE
         of the batch (cfg_split: one half of a CFG pair at b = 1) against the bank of the whole batch -- global frame row r
-        reads the reference features of bank batch r % bb whatever batch it belongs to (the tiling rule below)."""
+        reads the reference features of bank batch r % bb whatever batch it belongs to (the tiling rule below).
+        do_cfg == CLIP_BATCH: the b batch entries are INDEPENDENT clips, each evaluated exactly as a batch-1 call would
+        (FaceAnimatePipeline.call_batch): frame row r reads the bank of ITS clip, r // f."""
         n, L, Cd = x.shape
         b = n // video_length
         bb, _, row0 = bank_layout if bank_layout is not None else (b, 0, 0)
         a1 = self.attn1
         _, q, k, v = a1.qkv_ln(x, stats=stats)       # stats: norm1's statistics from proj_in's epilogue
-        if do_cfg == SKIP_BANK:
+        if do_cfg == CLIP_BATCH:
+            assert bank_layout is None
+            k2, v2 = cache.get(self, "bank_kv", lambda: a1.kv(bank.view(b, -1, L, Cd)[:, 0].to(x.dtype).contiguous()))
+            a = ops.attention(q, k, v, a1.heads, k2=k2, v2=v2, kv2_batch_div=video_length, kv2_batch_mod=0, kv2_first_batch=0,
+                              q_prescaled=True)
+        elif do_cfg == SKIP_BANK:
             # the uncond half of a CFG evaluation run on its own (FaceAnimatePipeline(cfg_split=True)): its rows attend to
             # themselves only (mutual_self_attention.py:264-284), the bank segment does not exist for this call
             a = ops.attention(q, k, v, a1.heads, q_prescaled=True)

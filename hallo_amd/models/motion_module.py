@@ -58,22 +58,26 @@ class TemporalTransformerBlock(nn.Module):
             self._ln.append(ops.fold_layernorm(norm.weight, norm.bias, attn.w_qkv, attn.b_qkv))
         self.ff.fold_norm(self.ff_norm)
 
-    def _pe_rows(self, i, attn, batch, frames):
-        """[batch*frames, 3C]: PE[f] @ W_qkv^T, the contribution of the positional encoding to q|k|v of frame f
-        (the reference adds PE to the normed activations, motion_module.py:459,573)."""
-        key = (i, batch, frames)
+    def _pe_rows(self, i, attn, batch, frames, lead=0):
+        """[batch*frames, 3C]: PE[f] @ W_qkv^T, the contribution of the positional encoding to q|k|v of temporal position f
+        (the reference adds PE to the normed activations, motion_module.py:459,573), one row per FRAME ROW of the activation:
+        positions 0..lead-1 of every batch entry first, then each entry's positions lead..frames-1 (ops.temporal_attention's
+        two-segment layout; lead = 0: entry b's positions at rows b * frames ..)."""
+        key = (i, batch, frames, lead)
         if key not in self._pe_bias:
             pe = attn.pos_encoder.pe32[:frames].to(attn.w_qkv.dtype)                       # the buffer follows the model dtype
             rows = ops.gemm(pe.contiguous(), attn.w_qkv)                                   # [frames, 3C]
-            self._pe_bias[key] = rows.repeat(batch, 1).contiguous()
+            self._pe_bias[key] = torch.cat([rows[:lead].repeat(batch, 1), rows[lead:].repeat(batch, 1)]).contiguous()
             ops.publish_constant()              # shared by every pipeline / stream that runs this module
         return self._pe_bias[key]
 
-    def run(self, h, batch, frames, drop=0, stats=None):
-        """h [batch*frames, L, C]; stats: the first norm's statistics of h from proj_in's epilogue, if any.  drop > 0 (batch 1 only): the caller discards the first `drop` frames of the result (the
-        motion frames put in front of the clip, unet_3d_blocks.py:696-748).  Everything behind the LAST temporal attention is
+    def run(self, h, batch, frames, drop=0, stats=None, lead=0):
+        """h [batch*frames, L, C]; stats: the first norm's statistics of h from proj_in's epilogue, if any.  lead: the first
+        `lead` temporal positions of all batch entries are stored at the front of h (ops.temporal_attention).  drop > 0: the
+        caller discards the first `drop` FRAME ROWS of the result (the motion frames put in front of the clips,
+        unet_3d_blocks.py:696-748: drop = batch * lead).  Everything behind the LAST temporal attention is
         row-wise (to_out, the feed-forward, proj_out), so those rows are not computed at all: the frames still take part as
-        keys / values, the kept rows are bit-for-bit what the full computation gives, and [frames - drop, L, C] is returned."""
+        keys / values, the kept rows are bit-for-bit what the full computation gives, and [batch*frames - drop, L, C] is returned."""
         n, L, Cd = h.shape
         last = len(self.attention_blocks) - 1
         for i, (attn, norm) in enumerate(zip(self.attention_blocks, self.norms)):
@@ -82,8 +86,8 @@ class TemporalTransformerBlock(nn.Module):
             h2 = h.view(n * L, Cd)
             qkv = ops.gemm(h2, wf, bf, ln_colsum=gcs, ln_eps=norm.eps,
                            ln_stats=ops.ln_stats(h2, 3 * Cd, norm.eps, bias2_rows_per_group=L, given=stats),
-                           bias2=self._pe_rows(i, attn, batch, frames), bias2_rows_per_group=L).view(n, L, 3 * Cd)
-            a = ops.temporal_attention(qkv, batch, frames, L, Cd, attn.heads)
+                           bias2=self._pe_rows(i, attn, batch, frames, lead), bias2_rows_per_group=L).view(n, L, 3 * Cd)
+            a = ops.temporal_attention(qkv, batch, frames, L, Cd, attn.heads, lead=lead)
             if drop and i == last:
                 a, h = a[drop:], h[drop:]
             # the next consumer of h is a LayerNorm-fused GEMM (the next attention's q|k|v, or the feed-forward): its statistics
@@ -107,9 +111,9 @@ class TemporalTransformer3DModel(nn.Module):
             [TemporalTransformerBlock(inner, heads, head_dim, n_attn, max_len) for _ in range(num_layers)])
         self.proj_out = Linear(inner, in_channels)
 
-    def run(self, x, batch, frames, drop=0):
+    def run(self, x, batch, frames, drop=0, lead=0):
         n, L, Cd = x.shape
-        assert drop == 0 or batch == 1
+        assert drop == 0 or drop == batch * lead or batch == 1
         h = self.norm.run(x)
         st = None
         if ops.wants_stats(n * L, 3 * self.inner, self.inner, bias2_rows_per_group=L):
@@ -119,7 +123,7 @@ class TemporalTransformer3DModel(nn.Module):
         h = h.view(n, L, self.inner)
         nb = len(self.transformer_blocks)
         for i, blk in enumerate(self.transformer_blocks):
-            h = blk.run(h, batch, frames, drop if i == nb - 1 else 0, stats=st if i == 0 else None)
+            h = blk.run(h, batch, frames, drop if i == nb - 1 else 0, stats=st if i == 0 else None, lead=lead)
         k = h.shape[0]                                       # n, or n - drop
         return self.proj_out.run(h.view(k * L, self.inner), residual=x[n - k:].view(k * L, Cd)).view(k, L, Cd)
 
@@ -133,5 +137,5 @@ class VanillaTemporalModule(nn.Module):
             in_channels, num_attention_heads, in_channels // num_attention_heads // temporal_attention_dim_div,
             num_transformer_block, len(attention_block_types), temporal_position_encoding_max_len, norm_num_groups)
 
-    def run(self, x, batch, frames, drop=0):
-        return self.temporal_transformer.run(x, batch, frames, drop)
+    def run(self, x, batch, frames, drop=0, lead=0):
+        return self.temporal_transformer.run(x, batch, frames, drop, lead)

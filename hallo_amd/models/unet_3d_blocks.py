@@ -83,30 +83,23 @@ def _layer(st, x, H, W, attn, audio, motion, depth):
     nm = mf.shape[1]
     Ft = nm + F
 
-    # [motion frames ; clip] buffer of this layer: the motion frames are per-clip constants, so the buffer lives in the clip
-    # cache with them already in place (round 4: was a fresh buffer + a copy2d launch per layer and step); every step only
-    # rewrites the clip's rows behind them.
+    # [motion frames ; clip] buffer of this layer (unet_3d_blocks.py:696-748 concatenates them in time per batch entry).  Here the
+    # motion frames of ALL batch entries sit at the front of the buffer and the clip frames of all entries behind them
+    # (ops.temporal_attention(lead=nm) reads a pixel's F' positions from the two segments in the reference's order): the clip rows
+    # are one contiguous [B*F, L, C] block at any batch size, so the audio module's output projection writes straight into it
+    # and the motion module's row-wise tail runs on it without a gather (round 6; a batch > 1 used to cost two copies of the
+    # activation per layer and step, and computed the rows of the motion frames that are sliced off).  The motion frames are
+    # per-clip constants: the buffer lives in the clip cache with them already in place (round 4).
     def cat_make():
-        c = torch.empty((B, Ft, L, Cd), device=x.device, dtype=x.dtype)
-        ops.copy2d(mf.view(B, nm * L * Cd), c.view(B, Ft * L * Cd), B, nm * L * Cd)
+        c = torch.empty((B * Ft, L, Cd), device=x.device, dtype=x.dtype)
+        ops.copy2d(mf.view(B * nm, L * Cd), c.view(B * Ft, L * Cd), B * nm, L * Cd)
         return c
     cat = st.cache.get(motion, "motion_cat", cat_make)
-    cat2 = cat.view(B, Ft * L * Cd)
     masks = st.masks[depth]
-    if B == 1:
-        # the audio module's output projection writes straight behind the motion frames
-        audio.run_audio(x, st.audio, masks, st.motion_scale, st.cache, out=cat.view(Ft * L, Cd)[nm * L:])
-    else:
-        x = audio.run_audio(x, st.audio, masks, st.motion_scale, st.cache)
-        ops.copy2d(x.view(B, F * L * Cd), cat2[:, nm * L * Cd:], B, F * L * Cd)
-    if B == 1:
-        # the motion frames' rows of the result would be sliced off: the module skips everything behind its last temporal
-        # attention for them (row-wise work, 2 of 18 frames)
-        return motion.run(cat.view(Ft, L, Cd), 1, Ft, drop=nm)
-    y = motion.run(cat.view(B * Ft, L, Cd), B, Ft)
-    out = torch.empty((n, L, Cd), device=x.device, dtype=x.dtype)
-    ops.copy2d(y.view(B, Ft * L * Cd)[:, nm * L * Cd:], out.view(B, F * L * Cd), B, F * L * Cd)
-    return out
+    audio.run_audio(x, st.audio, masks, st.motion_scale, st.cache, out=cat.view(B * Ft * L, Cd)[B * nm * L:])
+    # the motion frames' rows of the result would be sliced off: the module skips everything behind its last temporal
+    # attention for them (row-wise work, 2 of 18 frames)
+    return motion.run(cat, B, Ft, drop=B * nm, lead=nm)
 
 
 class CrossAttnDownBlock3D(nn.Module):

@@ -60,7 +60,7 @@ def option_epoch():
 
 ROUTING_OPTION_NAMES = ("gemm_variant", "split_k", "split_k_max", "v3_min_tiles", "gemm4", "gemm4_min_nk", "gemm_stage_min_tiles",
                         "gemm_rs", "ff_fused", "conv_fast", "attn40", "temporal_mfma", "attn_order", "tok_attn", "gn_fused", "xattn_tiled",
-                        "row_parts", "producer_stats")
+                        "row_parts", "producer_stats", "xattn_cap", "gemm_rs_dbg", "splitk_nt")
 
 
 def options_fingerprint():
@@ -397,16 +397,18 @@ def q_scale(head_dim):
     return head_dim ** -0.5 * LOG2E
 
 
-def temporal_attention(qkv, B, F, HW, Cdim, heads, *, out=None, scale=None):
-    """qkv [B*F, HW, 3C] -> out [B*F, HW, C]: per-pixel attention over the F axis."""
+def temporal_attention(qkv, B, F, HW, Cdim, heads, *, out=None, scale=None, lead=0):
+    """qkv [B*F, HW, 3C] -> out [B*F, HW, C]: per-pixel attention over the F axis.  lead > 0: the first `lead` temporal
+    positions of all B entries are stored at the front ([B*lead] frame rows), each entry's other F - lead positions behind them
+    (hallo_temporal_attention_lead)."""
     _chk_dev(qkv)
-    assert qkv.is_contiguous() and qkv.shape[-1] == 3 * Cdim
+    assert qkv.is_contiguous() and qkv.shape[-1] == 3 * Cdim and 0 <= lead < F
     if out is None:
         out = torch.empty((B * F, HW, Cdim), device=qkv.device, dtype=qkv.dtype)
     hd = Cdim // heads
     sc = float(scale if scale is not None else hd ** -0.5)
-    _l.check(_l.load().hallo_temporal_attention(_p(qkv), _p(out), B, F, HW, Cdim, heads, sc, dtype_code(qkv.dtype),
-                                                _stream()), "hallo_temporal_attention")
+    _l.check(_l.load().hallo_temporal_attention_lead(_p(qkv), _p(out), B, F, int(lead), HW, Cdim, heads, sc, dtype_code(qkv.dtype),
+                                                     _stream()), "hallo_temporal_attention_lead")
     return out
 
 

@@ -192,6 +192,17 @@ int hallo_attention(const hallo_attn_desc* d, void* stream);
  */
 int hallo_temporal_attention(const void* qkv, void* out, int B, int F, int HW, int C, int heads,
                              float scale, int dtype, void* stream);
+/* ABI v8 (round 6): the same attention over F' = lead + F_clip temporal positions per batch entry, for tensors whose frame rows are
+ * stored in TWO segments: the `lead` leading positions of ALL batch entries first (entry b's at frame rows [b * lead, (b + 1) * lead)),
+ * then the remaining F' - lead positions of entry b at frame rows B * lead + b * (F' - lead) + ...  The leading positions are the
+ * ReferenceNet features of the motion frames that the reference concatenates in time in front of every clip before a motion
+ * module and slices off after it (hallo/models/unet_3d_blocks.py:696-748, 1148-1202): with them at the front of the buffer the
+ * clip rows of a whole batch are ONE contiguous [B * F_clip, HW, C] block -- the audio module's output projection writes
+ * straight into it and the row-wise tail of the motion module runs on it without a gather, for any batch size (CFG pairs,
+ * batches of independent clips).  Key order per pixel is unchanged (leading positions first), so results equal the interleaved
+ * layout's bit for bit.  lead = 0 is hallo_temporal_attention. */
+int hallo_temporal_attention_lead(const void* qkv, void* out, int B, int F, int lead, int HW, int C, int heads,
+                                  float scale, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * hallo_groupnorm_nhwc: per-frame GroupNorm (+ optional SiLU) on [n_img, HW, C].

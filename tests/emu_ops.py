@@ -223,14 +223,25 @@ def attention(q, k1, v1, heads, *, k2=None, v2=None, kv2_batch_div=1, kv2_batch_
     return _store(res, out, q.dtype)
 
 
-def temporal_attention(qkv, B, Fr, HW, Cdim, heads, *, out=None, scale=None):
-    assert qkv.is_contiguous() and qkv.shape[-1] == 3 * Cdim and Fr <= 32
+def temporal_lead_rows(B, Fr, lead):
+    """Frame row of (batch entry b, temporal position f) in the two-segment layout of hallo_temporal_attention_lead
+    (include/hallo_amd.h): [B, Fr] long tensor."""
+    b = torch.arange(B)[:, None]
+    f = torch.arange(Fr)[None, :]
+    return torch.where(f < lead, b * lead + f, B * lead + b * (Fr - lead) + (f - lead))
+
+
+def temporal_attention(qkv, B, Fr, HW, Cdim, heads, *, out=None, scale=None, lead=0):
+    assert qkv.is_contiguous() and qkv.shape[-1] == 3 * Cdim and Fr <= 32 and 0 <= lead < Fr
     hd = Cdim // heads
     sc = float(scale if scale is not None else hd ** -0.5)
-    x = qkv.float().view(B, Fr, HW, 3, heads, hd).permute(3, 0, 2, 4, 1, 5)          # [3, B, HW, heads, F, hd]
+    rows = temporal_lead_rows(B, Fr, lead).reshape(-1).to(qkv.device)                 # (b, f) -> frame row
+    x = qkv.float()[rows].view(B, Fr, HW, 3, heads, hd).permute(3, 0, 2, 4, 1, 5)     # [3, B, HW, heads, F, hd]
     p = torch.softmax(x[0] @ x[1].transpose(-1, -2) * sc, dim=-1)
     o = (p @ x[2]).permute(0, 3, 1, 2, 4).reshape(B * Fr, HW, Cdim)
-    return _store(o, out, qkv.dtype)
+    res = torch.empty_like(o)
+    res[rows] = o
+    return _store(res, out, qkv.dtype)
 
 
 def groupnorm(x, gamma, beta, n_img, HW, groups, eps, *, silu=False, out=None):

@@ -392,3 +392,50 @@ def test_pipeline_call_variants(emu, oracle):
     assert torch.equal(vid4, vid)
     with pytest.raises(ValueError):
         pipe(*args, eta=0.5)
+
+
+@pytest.mark.parametrize("K,Fr", [(2, 2), (3, 3)])
+def test_pipeline_call_batch_equals_each_clip_alone(emu, oracle, K, Fr):
+    """FaceAnimatePipeline.call_batch (round 6): K independent clips through ONE denoising loop -- one UNet evaluation per step over
+    the K x F frames (hallo/models/unet_3d.py:510-527 takes any batch; the reference itself batches two evaluations for CFG,
+    hallo/animate/face_animate.py:397-417).  Every clip of the batch must come out as the oracle computes it ALONE
+    (H.animate at batch 1, no CFG) and as the native pipeline computes it alone: own banks (row r -> clip r // F), own face / audio
+    tokens, masks, latents, motion frames in the two-segment [all motion frames | all clips] layout of the motion modules."""
+    from oracle import harness as Hn
+    from oracle import hallo_ref as H
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.scheduler import DDIMScheduler
+    o, n = oracle, _native(oracle)
+    S, steps = 64, 2
+    ds = [Hn.clip_inputs(S, Fr, seed=100 + 7 * c) for c in range(K)]
+    for c, d in enumerate(ds):          # the harness draws the same latents / face region for every seed: make them per-clip too
+        d["latents"] = torch.randn(d["latents"].shape, generator=torch.Generator().manual_seed(200 + c))
+        d["face_mask"] = torch.roll(d["face_mask"], shifts=4 * c, dims=-1)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched)
+    clips = [dict(ref_image=d["ref_image"], face_emb=d["face_emb"], audio_tensor=d["audio"], face_mask=d["face_mask"],
+                  pixel_values_full_mask=d["full"], pixel_values_face_mask=d["face"], pixel_values_lip_mask=d["lip"],
+                  latents=d["latents"]) for d in ds]
+    seen = []
+    outs = pipe.call_batch(clips, S, S, Fr, steps, 1.0, motion_scale=ds[0]["motion_scale"],
+                           callback=lambda i, t, l: seen.append((int(t), l.float().clone())))
+    assert len(outs) == K and [t for t, _ in seen] == [999, 499] and seen[0][1].shape == (K, 4, Fr, S // 8, S // 8)
+    for c, d in enumerate(ds):
+        args = (d["ref_image"], d["face_emb"], d["audio"], d["face_mask"], d["full"], d["face"], d["lip"], S, S, Fr, steps, 1.0)
+        seen_o = []
+        with torch.no_grad():
+            vid_o = H.animate(o["vae"], o["reference_unet"], o["denoising_unet"], o["face_locator"], o["imageproj"],
+                              H.make_scheduler(), *args, motion_scale=d["motion_scale"], latents=d["latents"],
+                              callback=lambda i, t, l: seen_o.append(l.clone()))
+        vid_1 = pipe(*args, motion_scale=d["motion_scale"], latents=d["latents"]).videos
+        vid_b = outs[c].videos
+        assert vid_b.shape == vid_o.shape == (1, 3, Fr, S, S)
+        assert max(Hn.rel_l2(seen[i][1][c:c + 1], seen_o[i]) for i in range(steps)) < 1e-3
+        assert Hn.psnr(vid_b, vid_o) > 60.0 and Hn.psnr(vid_b, vid_1) > 60.0
+    assert Hn.psnr(outs[0].videos, outs[1].videos) < 40.0          # the clips ARE different
+    with pytest.raises(ValueError):
+        pipe.call_batch(clips, S, S, Fr, steps, 3.5)
+    lats = pipe.call_batch(clips, S, S, Fr, steps, 1.0, motion_scale=ds[0]["motion_scale"], decode=False)
+    assert len(lats) == K and lats[0].shape == (1, 4, Fr, S // 8, S // 8)

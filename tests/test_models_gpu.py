@@ -171,6 +171,67 @@ def test_pipeline_end_to_end(nets, guidance, cfg_split, report):
     assert p >= 35.0
 
 
+@pytest.mark.parametrize("K", [2, 3])
+def test_pipeline_call_batch(nets, K, report):
+    """FaceAnimatePipeline.call_batch (round 6): K independent clips through ONE denoising loop (every UNet evaluation over the
+    K x F frames: hallo/models/unet_3d.py:510-527 takes any batch; the reference batches two evaluations itself for CFG,
+    hallo/animate/face_animate.py:397-417).  Every clip of the batch against the fp32 oracle run on that clip ALONE
+    (per-step latents <= 5e-2, frames >= 35 dB) and against the native pipeline run on it alone (the kernels are row-wise /
+    per-frame / per-clip, so only tile-shape-dependent summation orders can differ: >= 50 dB); eager and hipGraph replay
+    (second batch on the graph captured during the first) byte-identical."""
+    dtype, o, n = nets
+    from oracle import harness as Hn
+    from oracle import hallo_ref as H
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.scheduler import DDIMScheduler
+    S, Fr, steps = 128, 4, 4
+    mk = lambda: DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                               prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    kw = dict(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+              face_locator=n["face_locator"], image_proj=n["imageproj"])
+    rd = lambda t: t.to(dtype).float()
+    ms = [1.0, 0.8, 1.2]
+
+    def inputs(seed):
+        d = Hn.clip_inputs(S, Fr, seed=seed)
+        d["latents"] = torch.randn(d["latents"].shape, generator=torch.Generator().manual_seed(seed + 1))
+        d["face_mask"] = torch.roll(d["face_mask"], shifts=8 * (seed % 3), dims=-1)
+        args = (rd(d["ref_image"]), rd(d["face_emb"]), rd(d["audio"]), d["face_mask"], [rd(m) for m in d["full"]],
+                [rd(m) for m in d["face"]], [rd(m) for m in d["lip"]])
+        clip = dict(zip(("ref_image", "face_emb", "audio_tensor", "face_mask", "pixel_values_full_mask", "pixel_values_face_mask",
+                         "pixel_values_lip_mask"), args), latents=rd(d["latents"]))
+        return args, clip
+    eager = FaceAnimatePipeline(scheduler=mk(), **kw)
+    graphed = FaceAnimatePipeline(scheduler=mk(), use_graph=True, **kw)
+    worst_lat, worst_psnr, worst_solo = 0.0, 99.0, 99.0
+    for rnd in range(2):                                   # round 1 replays the graph captured in round 0 on other clips
+        ins = [inputs(500 + 10 * rnd + c) for c in range(K)]
+        clips = [c for _, c in ins]
+        seen = []
+        out_e = eager.call_batch(clips, S, S, Fr, steps, 1.0, motion_scale=ms, callback=lambda i, t, l: seen.append(l.float().cpu()))
+        out_g = graphed.call_batch(clips, S, S, Fr, steps, 1.0, motion_scale=ms)
+        for c in range(K):
+            assert torch.equal(out_e[c].videos, out_g[c].videos), (rnd, c)
+            args = ins[c][0] + (S, S, Fr, steps, 1.0)
+            seen_o = []
+            vid_o = H.animate(o["vae"], o["reference_unet"], o["denoising_unet"], o["face_locator"], o["imageproj"],
+                              H.make_scheduler(), *args, motion_scale=ms, latents=clips[c]["latents"],
+                              callback=lambda i, t, l: seen_o.append(l.clone()))
+            worst_lat = max(worst_lat, max(Hn.rel_l2(seen[i][c:c + 1], seen_o[i]) for i in range(steps)))
+            worst_psnr = min(worst_psnr, Hn.psnr(out_e[c].videos, vid_o))
+            solo = eager(*args, motion_scale=ms, latents=clips[c]["latents"]).videos
+            worst_solo = min(worst_solo, Hn.psnr(out_e[c].videos, solo))
+    (sg,) = graphed._graphs.values()
+    assert sg.graph is not None and sg.replays == 2 * (steps - 1)
+    _rec(report, f"pipeline_call_batch_latents[K={K}]", dtype, worst_lat, 5e-2)
+    report.append({"test": f"pipeline_call_batch_frames[K={K}]", "dtype": str(dtype), "psnr_db_vs_oracle": worst_psnr,
+                   "psnr_db_vs_solo_run": worst_solo, "tol_psnr_db": 35.0, "graph_replay_byte_identical": True})
+    print("call_batch", K, worst_lat, worst_psnr, worst_solo)
+    assert worst_lat <= 5e-2 and worst_psnr >= 35.0 and worst_solo >= 50.0
+    with pytest.raises(ValueError):
+        eager.call_batch(clips, S, S, Fr, steps, 3.5)
+
+
 @pytest.mark.parametrize("guidance", [3.5, 1.0])
 def test_pipeline_hipgraph_replay_is_byte_identical(nets, guidance, report):
     """`use_graph=True`: the UNet evaluation is captured once and replayed for steps 1.. of every clip,

@@ -640,6 +640,34 @@ def test_temporal_attention(dtype, Cd, HW, Fr, B, report):
         ops.set_option("temporal_mfma", 2)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cd,HW,Fr,B,lead", [(320, 64, 18, 3, 2), (640, 16, 18, 2, 2), (1280, 4, 18, 4, 2), (320, 9, 10, 2, 1), (320, 5, 6, 1, 2)])
+def test_temporal_attention_lead_layout(dtype, Cd, HW, Fr, B, lead, report):
+    """hallo_temporal_attention_lead (ABI v8): the `lead` leading temporal positions of all batch entries stored at the front of the
+    buffer, the clip positions of every entry behind them -- the motion-frame layout of batched evaluations.  Per pixel the keys
+    are visited in the same order, so the result must equal the interleaved layout's BIT FOR BIT after the row permutation, in
+    all three kernels (LDS-staged, one wave per head, VALU)."""
+    from hallo_amd import ops
+    g = torch.Generator().manual_seed(Cd + HW + lead)
+    qkv = _rand((B * Fr, HW, 3 * Cd), dtype, g)                        # interleaved: entry b's F' positions are rows b F' ..
+    ref = ops.temporal_attention(qkv, B, Fr, HW, Cd, 8)
+    bb, ff = torch.arange(B)[:, None], torch.arange(Fr)[None, :]
+    rows = torch.where(ff < lead, bb * lead + ff, B * lead + bb * (Fr - lead) + (ff - lead)).reshape(-1).to(qkv.device)
+    q2 = torch.empty_like(qkv)
+    q2[rows] = qkv
+    for mode in (2, 1, 0):
+        ops.set_option("temporal_mfma", mode)
+        try:
+            out = ops.temporal_attention(q2, B, Fr, HW, Cd, 8, lead=lead)
+        finally:
+            ops.set_option("temporal_mfma", 2)
+        if mode:
+            assert torch.equal(out[rows], ref), mode
+        else:
+            _check(f"temporal_attn_lead_valu[{Cd},{HW},{Fr},{B},{lead}]", out[rows], ref, dtype, report)
+    report.append({"test": f"temporal_attn_lead[{Cd},{HW},{Fr},{B},{lead}]", "dtype": str(dtype), "bit_identical_to_interleaved": True})
+
+
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,HW,Cd,silu,eps", [(3, 256, 320, True, 1e-5), (2, 1024, 640, False, 1e-6), (2, 64, 2560, True, 1e-5),
