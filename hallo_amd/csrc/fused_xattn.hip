@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256, C == 320 ? (PF ? 2 : 3) : (C == 640 ? 2 : 1)) 
   __shared__ float s_gb[2][32];                                // G / B of the current batch (LDS: 32 registers fewer than copies per lane)
   __shared__ float s_ostat[4][2][64];                          // stats_out: per-wave partial (sum, sum of squares) of the output rows
   long cur_b = -1;
-  V8 st[NLD];
+  constexpr bool SPLIT_STAGE = !PF && C <= 640;      // stage a block in two halves (see step 1)
+  V8 st[SPLIT_STAGE ? (NLD + 1) / 2 : NLD];
   auto load_block = [&](int blk_) {
     const T* xb = reinterpret_cast<const T*>(p.x);
     const long r0 = (long)blk_ * 32;
@@ -214,7 +215,27 @@ __global__ __launch_bounds__(256, C == 320 ? (PF ? 2 : 3) : (C == 640 ? 2 : 1)) 
     }
 
     // ---- 1. x block -> LDS ----
-    {
+    if (!PF && SPLIT_STAGE) {
+      // C = 320 without prefetch / C = 640: the NLD staging registers on top of the resident Sg / OwP fragments do not fit the
+      // register budget of the occupancy cap (13-15 VGPRs spilled to scratch in round 5, hipcc -S).  Two half-blocks, each
+      // with all of ITS loads in flight: no scratch, and the block is still in flight as two groups of NLD / 2 16-byte loads.
+      const T* xb = reinterpret_cast<const T*>(p.x);
+      constexpr int H0 = NLD / 2;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int i0 = half ? H0 : 0, i1 = half ? NLD : H0;
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+          const int q = tid + 256 * i, r = q / CPR, cc = q - r * CPR;
+          st[i - i0] = ld8<T>(xb + min(row0 + r, p.rows - 1) * C + cc * 8);
+        }
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+          const int q = tid + 256 * i, r = q / CPR, cc = q - r * CPR;
+          *reinterpret_cast<V8*>(tile + r * PITCH + cc * 16) = st[i - i0];
+        }
+      }
+    } else {
       if (!PF) load_block(blk);
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {

@@ -865,15 +865,14 @@ __global__ __launch_bounds__(256) void row_parts_kernel(const T* __restrict__ C,
 }
 
 // gemm_variant: 0 v1 (register-staged 128x128), 1 / 2 v2 (LDS-DMA 128x128) with 1 / 2 LDS stages, 3 auto among v2 only,
-// 4 / 5 force the 256x320 / 128x320 kernel of gemm3.hip wherever it is applicable, 6 auto over everything (default),
-// 7 / 8 force the PERSISTENT 256x320 / 128x320 kernel for GEMM / GEGLU (convs fall back to the auto rule)
+// 4 / 5 force the 256x320 / 128x320 kernel of gemm3.hip wherever it is applicable, 6 auto over everything (default)
 static int g_gemm_variant = 6;
 static int g_split_k = 1;        // 0: never split K, 1: auto
 static int g_conv_fast = 1;      // 0: always use the general (per-thread tap) conv gather
 static int g_v3_min_tiles = 192; // auto: smallest grid (workgroups, 1 per CU) worth the big-tile kernel
 // Kernel picked by the last hallo_gemm / hallo_conv3x3_nhwc call, for per-symbol profiling (bench.py):
 // 1000 * LNF (gemm2: 0 none, 1 in-loop LayerNorm statistics, 2 external) + 100 * kernel (1 gemm_kernel, 2 gemm2_kernel,
-// 3 gemm3_kernel) + 10 * mode (0 gemm, 1 conv, 2 geglu) + stages / TM (+ 4 for the persistent gemm3 mode)
+// 3 gemm3_kernel) + 10 * mode (0 gemm, 1 conv, 2 geglu) + stages / TM
 static int g_last_kernel = 0;
 static int g_splitk_nt = 0;      // hallo_set_option("splitk_nt", 0 | 1 | 2): non-temporal split-K slab stores (+ loads): A/B of the slab's cache footprint with several clips in flight
 static int g_split_max = 16;         // hallo_set_option("split_k_max", n): cap of the split-K factor (slab traffic grows with it; under concurrency fewer, longer workgroups cost less than they do alone)
@@ -954,7 +953,6 @@ static int launch_gemm_impl(GemmArgs a, bool conv, bool geglu, int batch, void* 
     const float n_eff = (float)a.N / (float)(tn3 * (geglu ? 160 : 320));
     const int t256 = ((a.M + 255) / 256) * tn3 * batch, t128 = ((a.M + 127) / 128) * tn3 * batch;
     int tm = 0, sp = 1;
-    bool persist = false;
     // Split-K factor that brings a grid of `tiles` workgroups to ~one per CU (long K only; fp32 slabs + reduce pass).
     auto split_for = [&](int tiles) {
       if (tiles >= g_v3_min_tiles || geglu || lnf || batch != 1 || !g_split_k || !ws || nk < 16) return 1;
@@ -968,8 +966,6 @@ static int launch_gemm_impl(GemmArgs a, bool conv, bool geglu, int batch, void* 
     if (ok3) {
       if (v == 4) { tm = 2; sp = split_for(t256); }
       else if (v == 5) { tm = 1; sp = split_for(t128); }
-      else if (v == 7 && !conv) { tm = 2; sp = 1; persist = true; }
-      else if (v == 8 && !conv) { tm = 1; sp = 1; persist = true; }
       else if (n_eff > 0.8f) {
         // Auto rule, from tools/kernel_bench.py on MI355X (profiles/r1_kernel_bench_gemm_variants.txt): the big tile pays
         // when the K loop is long enough to amortise its prologue / 6-pass epilogue with one workgroup per CU:
@@ -1007,8 +1003,8 @@ static int launch_gemm_impl(GemmArgs a, bool conv, bool geglu, int batch, void* 
         a.slab = reinterpret_cast<float*>(ws);
       }
       g_last_splits = a.splits;
-      g_last_kernel = 300 + 10 * (geglu ? 2 : (conv ? 1 : 0)) + tm + (persist ? 4 : 0) + (lnf ? 2000 : 0);
-      launch_gemm3<T>(a, geglu ? 2 : (conv ? 1 : 0), tm, batch, st, persist);
+      g_last_kernel = 300 + 10 * (geglu ? 2 : (conv ? 1 : 0)) + tm + (lnf ? 2000 : 0);
+      launch_gemm3<T>(a, geglu ? 2 : (conv ? 1 : 0), tm, batch, st);
       HALLO_CHECK_LAUNCH();
       if (a.splits > 1) {
         const long n = (long)a.M * (a.N / 8);
@@ -1134,6 +1130,10 @@ extern "C" int hallo_gemm(const hallo_gemm_desc* d, void* stream) {
   if (a.ln_colsum && (d->batch != 1 || d->out_f32 || d->bias_per_row)) return -22;
   a.ln_parts = (a.ln_colsum && a.ln_stats && d->ln_parts > 0) ? d->ln_parts : 0;
   if (d->ln_parts < 0 || (d->ln_parts > 0 && (!(d->ln_colsum && d->ln_stats) || (reinterpret_cast<uintptr_t>(d->ln_stats) & 15)))) return -22;
+  // the partial sums are one (sum, sum of squares) pair per 64-column block of A's K columns -- nothing else makes mean = sum / K
+  // right -- and a tile's rows x ln_parts pairs are staged in the (idle) operand LDS behind the K loop: 128 rows x 32 pairs fill the
+  // 32 KB of the 1-stage 128 x 128 kernel (K <= 2048; the widest LayerNorm on the path is 1280).  Larger K: hallo_row_stats.
+  if (d->ln_parts > 0 && (d->ln_parts != (d->K + 63) / 64 || d->ln_parts > 32)) return -22;
   a.ws_zeroed = d->workspace_zeroed != 0;
   a.row_parts = d->row_parts;
   if (a.row_parts && (d->batch != 1 || d->out_f32 || d->geglu || (d->N & 7) || (reinterpret_cast<uintptr_t>(d->row_parts) & 15))) return -22;
@@ -1215,6 +1215,13 @@ extern "C" int hallo_get_option_attn(const char* name);   // attention.hip
 
 extern "C" void hallo_gemm4_debug_buffer(long long* p) { set_gemm4_debug_buffer(p); }   // tools/cbench: s_memtime stamps of gemm4.hip
 
+extern "C" const char* hallo_option_names(void) {
+  // every name hallo_set_option accepts (this file, attention.hip, fused_xattn.hip, norm_elementwise.hip); tests/test_abi.py
+  // checks that each one round-trips through hallo_get_option / hallo_set_option
+  return "gemm_variant,split_k,split_k_max,splitk_nt,v3_min_tiles,conv_fast,row_parts,producer_stats,gemm_rs,gemm4,gemm4_min_nk,"
+         "gemm_stage_min_tiles,ff_fused,gemm_rs_dbg,attn40,temporal_mfma,attn_order,tok_attn,xattn_tiled,xattn_cap,gn_fused";
+}
+
 extern "C" int hallo_get_option(const char* name) {
   if (!name) return -22;
   if (!strcmp(name, "gemm_variant")) return g_gemm_variant;
@@ -1238,7 +1245,7 @@ extern "C" int hallo_get_option(const char* name) {
 
 extern "C" int hallo_set_option(const char* name, int value) {
   if (!name) return -22;
-  if (!strcmp(name, "gemm_variant")) { if (value < 0 || value > 8) return -22; g_gemm_variant = value; return 0; }
+  if (!strcmp(name, "gemm_variant")) { if (value < 0 || value > 6) return -22; g_gemm_variant = value; return 0; }
   if (!strcmp(name, "v3_min_tiles")) { if (value < 1) return -22; g_v3_min_tiles = value; return 0; }
   if (!strcmp(name, "conv_fast")) { if (value < 0 || value > 1) return -22; g_conv_fast = value; return 0; }
   if (!strcmp(name, "split_k")) { if (value < 0 || value > 1) return -22; g_split_k = value; return 0; }

@@ -37,13 +37,10 @@ constexpr unsigned G3_OOB = 0xFFFFFFFFu;
 #define G3_BLOAD(rs, ldsptr, voff, soff) \
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(ldsptr), 16, (int)(voff), (int)(soff), 0, 0)
 
-// PERSIST: one workgroup per CU walks the tile list (tile = it * gridDim.x + blockIdx.x, XCD-remapped).  The DMA of the
-// NEXT tile's first K step is issued before the epilogue of the current tile -- into slot 1, the epilogue's
-// transposition scratch lives in slot 0 -- so the prologue latency of a tile hides under the previous tile's epilogue
-// and its stores drain under the next tile's MFMAs.  This is what makes the big tile pay on the SHORT-K projections
-// (K = 320 / 640: 5 / 10 K steps per tile), where a one-shot workgroup per CU spends as long in prologue + epilogue
-// as in the K loop and nothing overlaps them.
-template <typename T, int MODE /*0 gemm, 1 conv3x3 (fast gather), 2 geglu*/, int TM, bool PERSIST>
+// (A persistent form -- one workgroup per CU walking the tile list with the next tile's first K step prefetched under the
+// epilogue -- existed in rounds 1-5 behind gemm_variant 7 / 8: next to 160 accumulator registers its loader state spilled 201
+// VGPRs, it never won an A/B and no routing rule selected it.  Removed in round 6.)
+template <typename T, int MODE /*0 gemm, 1 conv3x3 (fast gather), 2 geglu*/, int TM>
 __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
@@ -59,14 +56,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   // into the first two so that the last piece has half a step to land before the next step's vmcnt(0)
   constexpr int PPK = G3_FRONT ? (NP + 1) / 2 : (NP + 3) / 4;
   constexpr int SLOT = (BM + G3_BN) * G3_BK;
-  // persistent mode keeps slot 1 clear of the 64 KB epilogue scratch at the start of the array
-  constexpr int SLOT_STRIDE = (PERSIST && SLOT < 32768) ? 32768 : SLOT;
+  constexpr int SLOT_STRIDE = SLOT;
   __shared__ __attribute__((aligned(16))) T smem[SLOT_STRIDE + SLOT];
   // GemmArgs::ln_parts > 0 (round 5): ln_stats holds the producer's partial (sum, sum of squares) per 64-column block of A's rows;
-  // (mean, rstd) of this tile's rows are reduced here in slot order.  Two buffers by tile parity: in persistent mode a fast wave
-  // is in the next tile's prologue while a slow one still reads this tile's values in its epilogue (the K loop's barriers order
-  // everything two tiles apart).
-  __shared__ float s_ln[CONV ? 2 : 2 * 2 * BM];
+  // (mean, rstd) of this tile's rows are reduced here in slot order.
+  __shared__ float s_ln[CONV ? 2 : 2 * BM];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -161,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
     }
     rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Abase), 0, clamp32(a_bytes), 0x00020000);
   };
-  auto slot_of = [&](int kt) { return PERSIST ? ((kt + 1) & 1) : (kt & 1); };
+  auto slot_of = [&](int kt) { return kt & 1; };
 
   // DMA piece i of K tile kt into slot `buf`: i < NW -> W slab i, else A slab i - NW
   int soffW = 0, soffA = 0;
@@ -195,10 +189,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   const int fa_row = (wm * 32 * TM + l31) * G3_BK;
   const int fw_row = (wn * 160 + l31) * G3_BK;
 
-  bool prefetched = false;      // PERSIST: K step 0 of this tile was issued before the previous tile's epilogue
-  for (int it = 0;; ++it) {
-  const int vt = PERSIST ? it * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x;
-  if (vt >= nwg) break;
+  const int vt = (int)blockIdx.x;
+  if (vt >= nwg) return;
   const int bid = xcd_remap(vt, nwg);
   const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
   const int m0 = tile_m * BM;
@@ -212,10 +204,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  // (persistent mode recomputes the loader state here even when K step 0 was prefetched: keeping it live across the
-  // previous tile's epilogue costs ~20 registers next to 160 accumulators and spills)
   setup_loader(tile_m, tile_n);
-  if (!prefetched && kt_begin < kt_end) {
+  if (kt_begin < kt_end) {
     stage_begin(kt_begin);
 #pragma unroll
     for (int i = 0; i < NP; ++i) stage_piece(i, slot_of(kt_begin));
@@ -286,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
   __builtin_amdgcn_s_barrier();   // every wave is done with the staging LDS: the epilogue reuses it
   if (!CONV && p.ln_parts > 0 && p.ln_colsum != nullptr) {
     // the producer's partial (sum, sum of squares) per 64-column block of this tile's A rows -> (mean, rstd) per row: coalesced
-    // 16-byte loads into slot 0 (idle; the persistent prefetch below goes to slot 1), then thread r reduces row r in slot order
+    // 16-byte loads into slot 0 (idle), then thread r reduces row r in slot order
     const int P2 = p.ln_parts * 2;
     const int rows = min(BM, p.M - m0);
     const int nflt = rows * P2, nvec = nflt >> 2;           // whole 16-byte pieces, then the (<= 3 floats) tail: nothing is read past the rows' partials
@@ -300,24 +290,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
       float sm = 0.0f, sq = 0.0f;
       for (int i = 0; i < P2; i += 2) { sm += pr[i]; sq += pr[i + 1]; }
       const float mean = sm / (float)p.K;
-      s_ln[(it & 1) * 2 * BM + 2 * tid] = mean;
-      s_ln[(it & 1) * 2 * BM + 2 * tid + 1] = rsqrtf(fmaxf(sq / (float)p.K - mean * mean, 0.0f) + p.ln_eps);
+      s_ln[2 * tid] = mean;
+      s_ln[2 * tid + 1] = rsqrtf(fmaxf(sq / (float)p.K - mean * mean, 0.0f) + p.ln_eps);
     }
     __syncthreads();
   }
-  if (PERSIST) {
-    // next tile of this workgroup: loader state + DMA of its K step 0 into slot 1 (the epilogue scratch is in slot 0)
-    const int nvt = vt + (int)gridDim.x;
-    prefetched = nvt < nwg;
-    if (prefetched) {
-      const int nb = xcd_remap(nvt, nwg);
-      setup_loader(nb / p.tiles_n, nb % p.tiles_n);
-      stage_begin(0);
-#pragma unroll
-      for (int i = 0; i < NP; ++i) stage_piece(i, slot_of(0));
-    }
-  }
-
   // ---- epilogue ----
   const bool lnf = !CONV && p.ln_colsum != nullptr && p.ln_stats != nullptr && p.splits <= 1;
   const T* bias = reinterpret_cast<const T*>(p.bias);
@@ -382,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
           if (lane_on && m < p.M && n < p.N) {
             float vs = GELU_U_INV, gs = GELU_U_SCALE, vc = 0.0f, gc = 0.0f;      // out = scale * acc + shift * G[n] + bias'
             if (lnf) {
-              const int lr = (it & 1) * 2 * BM + 2 * (wm * 32 * TM + tm * 32 + rr);
+              const int lr = 2 * (wm * 32 * TM + tm * 32 + rr);
               const float mean = p.ln_parts > 0 ? s_ln[lr] : p.ln_stats[2 * (long)m];
               const float rstd = p.ln_parts > 0 ? s_ln[lr + 1] : p.ln_stats[2 * (long)m + 1];
               vs *= rstd; gs *= rstd; vc = -mean * vs; gc = -mean * gs;
@@ -452,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
         float t8[8];
         const float br = (bias && p.bias_per_row) ? to_f32(bias[m]) : 0.0f;
         if (lnf) {       // fused LayerNorm: rstd * (acc - mean * G[n]) with the statistics of hallo_row_stats (or the producer's partial sums)
-          const int lr = (it & 1) * 2 * BM + 2 * (wm * 32 * TM + tm * 32 + rr);
+          const int lr = 2 * (wm * 32 * TM + tm * 32 + rr);
           const float mean = p.ln_parts > 0 ? s_ln[lr] : p.ln_stats[2 * (long)m];
           const float rstd = p.ln_parts > 0 ? s_ln[lr + 1] : p.ln_stats[2 * (long)m + 1];
           const float c1 = -mean * rstd;
@@ -499,52 +476,25 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
     }
   }
   }   // !GEGLU
-  if (!PERSIST) break;
-  // The next tile's K step 1 is DMA'd into slot 0 (= this epilogue's scratch) only after the barrier at the top of its
-  // K step 0, which every wave reaches after finishing its epilogue; its scratch READS are retired here.
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }   // tile loop
 }
 #undef G3_BLOAD
 
-static int num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-    else n = 256;
-  }
-  return n;
-}
-
 template <typename T>
-void launch_gemm3(const GemmArgs& a, int mode, int tm, int batch, hipStream_t st, bool persist) {
+void launch_gemm3(const GemmArgs& a, int mode, int tm, int batch, hipStream_t st) {
   const int tiles = a.tiles_m * a.tiles_n;
   dim3 block(512);
-  if (persist && mode != 1) {
-    // one workgroup per CU (147 / 131 KB of LDS each) walking the tile list
-    dim3 grid(tiles < num_cus() ? tiles : num_cus(), 1, batch);
-    if (tm == 2) {
-      if (mode == 2) hipLaunchKernelGGL((gemm3_kernel<T, 2, 2, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((gemm3_kernel<T, 0, 2, true>), grid, block, 0, st, a);
-    } else {
-      if (mode == 2) hipLaunchKernelGGL((gemm3_kernel<T, 2, 1, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((gemm3_kernel<T, 0, 1, true>), grid, block, 0, st, a);
-    }
-    return;
-  }
   dim3 grid(tiles, a.splits, batch);
   if (tm == 2) {
-    if (mode == 2) hipLaunchKernelGGL((gemm3_kernel<T, 2, 2, false>), grid, block, 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((gemm3_kernel<T, 1, 2, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((gemm3_kernel<T, 0, 2, false>), grid, block, 0, st, a);
+    if (mode == 2) hipLaunchKernelGGL((gemm3_kernel<T, 2, 2>), grid, block, 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((gemm3_kernel<T, 1, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm3_kernel<T, 0, 2>), grid, block, 0, st, a);
   } else {
-    if (mode == 2) hipLaunchKernelGGL((gemm3_kernel<T, 2, 1, false>), grid, block, 0, st, a);
-    else if (mode == 1) hipLaunchKernelGGL((gemm3_kernel<T, 1, 1, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((gemm3_kernel<T, 0, 1, false>), grid, block, 0, st, a);
+    if (mode == 2) hipLaunchKernelGGL((gemm3_kernel<T, 2, 1>), grid, block, 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((gemm3_kernel<T, 1, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm3_kernel<T, 0, 1>), grid, block, 0, st, a);
   }
 }
-template void launch_gemm3<_Float16>(const GemmArgs&, int, int, int, hipStream_t, bool);
-template void launch_gemm3<__bf16>(const GemmArgs&, int, int, int, hipStream_t, bool);
+template void launch_gemm3<_Float16>(const GemmArgs&, int, int, int, hipStream_t);
+template void launch_gemm3<__bf16>(const GemmArgs&, int, int, int, hipStream_t);
 
 }  // namespace hallo

@@ -41,9 +41,7 @@ struct GemmArgs {
 
 // gemm3.hip: 256x320 / 128x320 tile kernel (8 waves, LDS-DMA, one barrier per K step).  MODE 0 gemm, 1 conv3x3
 // (fast gather only: Cin % 64 == 0, no upsample), 2 geglu.  TM = 32-row blocks per wave along M (2 or 1).
-// persist: one workgroup per CU walks the tile list with the next tile's first K step prefetched under the epilogue
-// (gemm / geglu only, no split-K).
-template <typename T> void launch_gemm3(const GemmArgs& a, int mode, int tm, int batch, hipStream_t st, bool persist);
+template <typename T> void launch_gemm3(const GemmArgs& a, int mode, int tm, int batch, hipStream_t st);
 
 // gemm_rs.hip: row-stationary kernel for K = 320 / 640 (A rows of a workgroup in registers, LayerNorm statistics computed
 // from them, W streamed through an LDS ring).  gemm_rs_eligible() is the routing rule of launch_gemm().

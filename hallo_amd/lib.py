@@ -105,6 +105,7 @@ SYMBOLS = {
     "hallo_abi_version": (C.c_int, []),
     "hallo_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "hallo_get_option": (C.c_int, [C.c_char_p]),
+    "hallo_option_names": (C.c_char_p, []),
     "hallo_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "hallo_gemm_fp8": (C.c_int, [C.POINTER(GemmFp8Desc), C.c_void_p]),
     "hallo_quant_rows_fp8": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,

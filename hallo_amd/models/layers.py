@@ -94,6 +94,10 @@ class HalloModule(nn.Module):
                 m._prepare()
         if hasattr(self, "_prepare"):
             self._prepare()
+        # the weight images were built on the CURRENT stream; other pipelines read them from theirs with no ordering against it
+        # (FaceAnimatePipeline objects on several streams share the networks): make the build visible with a one-off host wait
+        # (refused inside a graph capture, where the images would also land in the graph's private pool) -- ADVICE r5
+        ops.publish_constant()
         self._prepared = True
         self.prepare_epoch += 1
         return self

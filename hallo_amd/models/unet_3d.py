@@ -180,6 +180,7 @@ class UNet3DConditionModel(HalloModule):
                 m.set_fp8(enabled)
                 n += 1
         self.fp8_projections = bool(enabled)
+        ops.publish_constant()          # the quantised images were built on this stream; other pipelines' streams read them
         return n
 
     def set_attention_slice(self, slice_size):

@@ -5,6 +5,7 @@ stream; every computation goes through the hand-written gfx950 kernels.  Activat
 token-major: [frames, H*W, C] with C contiguous.
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -58,16 +59,17 @@ def option_epoch():
     return _option_epoch
 
 
-ROUTING_OPTION_NAMES = ("gemm_variant", "split_k", "split_k_max", "v3_min_tiles", "gemm4", "gemm4_min_nk", "gemm_stage_min_tiles",
-                        "gemm_rs", "ff_fused", "conv_fast", "attn40", "temporal_mfma", "attn_order", "tok_attn", "gn_fused", "xattn_tiled",
-                        "row_parts", "producer_stats", "xattn_cap", "gemm_rs_dbg", "splitk_nt")
+def routing_option_names():
+    """Every settable option of the library, from the library itself (hallo_option_names, ABI v8): an option added to a kernel file
+    is part of the graph key without anybody remembering a Python tuple ('xattn_cap' was missing from one)."""
+    return tuple(n for n in _l.load().hallo_option_names().decode().split(",") if n)
 
 
 def options_fingerprint():
     """Values of every option that decides which kernel a launch is routed to: what a captured graph is valid for (the epoch
     counts CHANGES, and a routing scope that sets and restores options changes it twice per clip without changing anything)."""
     lib = _l.load()
-    return tuple(lib.hallo_get_option(n.encode()) for n in ROUTING_OPTION_NAMES)
+    return tuple(lib.hallo_get_option(n.encode()) for n in routing_option_names())
 
 
 # Kernel routing for THROUGHPUT: several independent clips in flight on one GPU (bench.py --inflight, DESIGN section 7.1).  The
@@ -90,23 +92,36 @@ class routing:
     (FaceAnimatePipeline(routing=...)) instead of process-global state: the options are read by the library at ENQUEUE time (and
     baked into a graph at capture time), so a scope around the enqueue calls is all a pipeline needs; the previous values come
     back on exit, and an option that already has the wanted value is not touched (no epoch bump, captured graphs stay valid).
-    None = leave everything as it is.  Host-side only: two host threads enqueueing under different routings must serialise."""
+    None = leave everything as it is.  The options live in the library (one set per process), so a scope HOLDS a process-wide
+    re-entrant lock from entry to exit -- also a `None` scope, whose launches must not see another thread's routing either: a
+    second host thread that enters a scope while the first is enqueueing a clip waits for it (enqueueing a clip is ~150 ms of
+    host work; the GPU work it queued runs on regardless).  Nested scopes of one thread are fine."""
+
+    _lock = threading.RLock()
 
     def __init__(self, options):
         self.options = ROUTINGS[options] if isinstance(options, str) else options
         self._prev = None
 
     def __enter__(self):
-        if self.options:
-            self._prev = {k: set_option(k, v) for k, v in self.options.items()}
+        routing._lock.acquire()
+        try:
+            if self.options:
+                self._prev = {k: set_option(k, v) for k, v in self.options.items()}
+        except BaseException:
+            routing._lock.release()
+            raise
         return self
 
     def __exit__(self, *exc):
-        if self._prev:
-            for k, v in self._prev.items():
-                if v is not None:
-                    set_option(k, v)
-        self._prev = None
+        try:
+            if self._prev:
+                for k, v in self._prev.items():
+                    if v is not None:
+                        set_option(k, v)
+            self._prev = None
+        finally:
+            routing._lock.release()
         return False
 
 
@@ -148,11 +163,19 @@ class Scratch:
         if self.gn.numel() < need:
             if torch.cuda.is_current_stream_capturing():
                 raise _l.HalloLibraryError(f"GroupNorm scratch of {need} floats needed inside a graph capture, {self.gn.numel()} allocated")
+            # a graph captured earlier under this scratch has the OLD address baked in and may still be replayed: the old buffer
+            # stays alive (and private to this scratch) for as long as the scratch does
+            self._retired = getattr(self, "_retired", []) + [self.gn]
             self.gn = torch.empty(need, device=self.device, dtype=torch.float32)
         return self.gn
 
 
-_scratch_stack = []
+class _ScratchTLS(threading.local):
+    def __init__(self):
+        self.stack = []
+
+
+_scratch_tls = _ScratchTLS()      # per host thread: two threads driving two pipelines never see each other's scope
 _stream_scratch = {}
 
 
@@ -167,16 +190,16 @@ class scratch_scope:
         self.scratch = scratch
 
     def __enter__(self):
-        _scratch_stack.append(self.scratch)
+        _scratch_tls.stack.append(self.scratch)
         return self.scratch
 
     def __exit__(self, *exc):
-        _scratch_stack.pop()
+        _scratch_tls.stack.pop()
         return False
 
 
 def current_scratch(device):
-    for s in reversed(_scratch_stack):            # the innermost scope that names a scratch (a None scope changes nothing)
+    for s in reversed(_scratch_tls.stack):        # the innermost scope of THIS thread that names a scratch (a None scope changes nothing)
         if s is not None:
             return s
     device = torch.device(device)

@@ -37,7 +37,7 @@ int hallo_abi_version(void);
 
 /* Tuning / A-B switch (not part of the numerical contract): "gemm_variant" = 0 register-staged 128x128 kernel,
  * 1 / 2 direct-to-LDS 128x128 kernel with 1 / 2 LDS stages, 3 auto among those, 4 / 5 force the 256x320 / 128x320
- * big-tile kernel wherever applicable, 6 auto over all (default), 7 / 8 force the persistent big-tile mode for GEMM / GEGLU;
+ * big-tile kernel wherever applicable, 6 auto over all (default);
  * "split_k" = 0 / 1 (auto, default); "gn_fused" = 0 / 1 (single-launch GroupNorm for small feature maps, default 1);
  * "v3_min_tiles" = smallest grid the auto rule gives to the big-tile kernel; round 4: "gemm4" = 0 off / 1 auto rule / 2 every
  * problem csrc/gemm4.hip covers, "gemm4_min_nk", "gemm_stage_min_tiles", "split_k_max" (cap of the split-K factor).
@@ -45,8 +45,11 @@ int hallo_abi_version(void);
 int hallo_set_option(const char* name, int value);
 /* Read an option back; "last_gemm_kernel" = the kernel the last hallo_gemm / hallo_conv3x3_nhwc call launched, as
  * 1000 * f + 100 * k + 10 * mode + s: k = 1 gemm_kernel / 2 gemm2_kernel / 3 gemm3_kernel, mode = 0 gemm / 1 conv3x3 /
- * 2 geglu, s = LDS stages (gemm2) or TM (gemm3; + 4 = persistent), f = fused-LayerNorm form of gemm2 (0 / 1 / 2).  Used by bench.py to report achieved rates per kernel SYMBOL.  -22 = unknown. */
+ * 2 geglu, s = LDS stages (gemm2) or TM (gemm3), f = fused-LayerNorm form of gemm2 (0 / 1 / 2).  Used by bench.py to report achieved rates per kernel SYMBOL.  -22 = unknown. */
 int hallo_get_option(const char* name);
+/* ABI v8: the names of every option hallo_set_option accepts, comma-separated (static storage).  A host that caches launch
+ * sequences (hipGraphs of a UNet evaluation) keys them on the VALUES of all of these. */
+const char* hallo_option_names(void);
 
 /* ------------------------------------------------------------------------------------------
  * hallo_gemm: C[M,N] = act( alpha * rowscale[m] * (A[M,K] . W[N,K]^T + bias) + residual )

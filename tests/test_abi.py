@@ -19,7 +19,7 @@ def lib():
 def test_header_symbols_are_exported(lib):
     from hallo_amd import lib as hl
     hdr = open(os.path.join(ROOT, "include", "hallo_amd.h")).read()
-    declared = set(re.findall(r"^(?:int|int64_t)\s+(hallo_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(hallo_\w+)\s*\(", hdr, flags=re.M))
     assert declared, "no declarations parsed from include/hallo_amd.h"
     assert declared == set(hl.SYMBOLS), (declared ^ set(hl.SYMBOLS))
     for name in declared:
@@ -87,6 +87,13 @@ def test_every_entry_point_rejects_bad_arguments(lib):
     d.K=16; d.lda=12; res['gemm_lda']=lib.hallo_gemm(C.byref(d),N)
     d.lda=16; d.act=7; res['gemm_act']=lib.hallo_gemm(C.byref(d),N)
     d.act=0; d.dtype=5; res['gemm_dtype']=lib.hallo_gemm(C.byref(d),N)
+    # ln_parts: one (sum, sum of squares) pair per 64-column block of K, at most 32 of them (the staging LDS of a tile)
+    d=L.GemmDesc(); d.A=d.B=d.C=p.value; d.M=128; d.N=128; d.K=320; d.lda=d.ldb=320; d.ldc=128; d.batch=1
+    d.ln_colsum=p.value; d.ln_stats=p.value; d.ln_eps=1e-5
+    d.ln_parts=4; res['gemm_ln_parts_not_K_over_64']=lib.hallo_gemm(C.byref(d),N)
+    d.K=2560; d.lda=d.ldb=2560; d.ln_parts=40; res['gemm_ln_parts_over_32']=lib.hallo_gemm(C.byref(d),N)
+    res['temporal_lead_neg']=lib.hallo_temporal_attention_lead(p,p,2,18,-1,4,80,2,1.0,0,N)
+    res['temporal_lead_all']=lib.hallo_temporal_attention_lead(p,p,2,18,18,4,80,2,1.0,0,N)
     c=L.ConvDesc(); res['conv_zero']=lib.hallo_conv3x3_nhwc(C.byref(c),N); res['conv_null']=lib.hallo_conv3x3_nhwc(None,N)
     a=L.AttnDesc(); res['attn_zero']=lib.hallo_attention(C.byref(a),N); res['attn_null']=lib.hallo_attention(None,N)
     a=L.AttnDesc(); a.q=a.k1=a.v1=a.o=p.value; a.batch=1; a.heads=2; a.head_dim=64; a.Lq=8; a.Lkv1=8

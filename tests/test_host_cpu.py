@@ -207,7 +207,7 @@ def test_routing_is_a_scope_not_process_state():
     finally:
         ops.set_option("split_k_max", user_prev)
     assert ops.options_fingerprint() == base
-    assert inside != before and len(base) == len(ops.ROUTING_OPTION_NAMES) and all(v >= 0 for v in base)
+    assert inside != before and len(base) == len(ops.routing_option_names()) >= 21 and all(v >= 0 for v in base)
 
 
 def test_rank_core_slices_respect_the_cgroup_quota():
@@ -242,10 +242,70 @@ def test_scratch_scope_selects_the_pipelines_own_scratch():
                 assert ops.current_scratch("cpu") is b
             assert ops.current_scratch("cpu") is b
         assert ops.current_scratch("cpu") is a
-    assert not ops._scratch_stack
+    assert not ops._scratch_tls.stack
     try:
         with ops.scratch_scope(a):
             raise RuntimeError("x")
     except RuntimeError:
         pass
-    assert not ops._scratch_stack          # unwound on exceptions too
+    assert not ops._scratch_tls.stack      # unwound on exceptions too
+
+
+def test_scratch_scope_and_routing_are_safe_across_host_threads():
+    """two host threads driving two pipelines.  The scratch scope stack is per thread (a thread never launches
+    with another pipeline's split-K slab / GroupNorm scratch, and never pops the other's entry); the kernel routing is process
+    state inside the library, so a routing scope holds a process-wide re-entrant lock: the second thread's scope starts when the
+    first one's has ended, each sees ITS option values for the whole of its scope."""
+    import threading
+    import time
+    from hallo_amd import ops
+
+    class Fake:
+        def __init__(self, tag):
+            self.splitk = tag
+    seen, errs = {}, []
+    gate = threading.Barrier(2)
+    base = ops.options_fingerprint()
+
+    def work(tag, opts, hold):
+        try:
+            gate.wait()
+            with ops.routing(opts), ops.scratch_scope(Fake(tag)):
+                for _ in range(5):
+                    assert ops._workspace("cpu") == tag                       # never the other thread's scratch
+                    assert ops.get_option("split_k_max") == opts["split_k_max"]   # never the other thread's routing
+                    time.sleep(hold)
+                with ops.routing(opts):                                       # re-entrant for the owner
+                    assert ops.get_option("gemm_rs") == opts["gemm_rs"]
+                seen[tag] = ops.options_fingerprint()
+        except Exception as e:      # noqa: BLE001
+            errs.append((tag, repr(e)))
+    ta = threading.Thread(target=work, args=("a", dict(ops.THROUGHPUT_OPTIONS, split_k_max=3), 0.01))
+    tb = threading.Thread(target=work, args=("b", dict(ops.LATENCY_OPTIONS, split_k_max=7), 0.01))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert not errs, errs
+    assert seen["a"] != seen["b"] and ops.options_fingerprint() == base and not ops._scratch_tls.stack
+
+
+def test_option_names_export_is_exhaustive(lib=None):
+    """hallo_option_names (ABI v8): every listed option reads back through hallo_get_option and accepts its own value; the graph key
+    of FaceAnimatePipeline is built from this list (a hand-kept tuple had missed 'xattn_cap')."""
+    from hallo_amd import lib as L, ops
+    lib = L.load()
+    names = ops.routing_option_names()
+    assert len(names) == len(set(names)) >= 21 and {"xattn_cap", "gemm_rs_dbg", "splitk_nt", "split_k_max", "gn_fused"} <= set(names)
+    for n in names:
+        v = lib.hallo_get_option(n.encode())
+        assert v >= 0, n
+        assert lib.hallo_set_option(n.encode(), v) == 0, n
+    # and no settable option is missing from the list: the names in the sources' strcmp chains
+    import os
+    import re
+    src = os.path.join(os.path.dirname(L.__file__), "csrc")
+    found = set()
+    for f in os.listdir(src):
+        if f.endswith(".hip"):
+            txt = open(os.path.join(src, f)).read()
+            for m in re.finditer(r'strcmp\(name, "([a-z0-9_]+)"\)\)\s*(?:\|\|[^)]*\)\))?\s*\{\s*if \(value', txt):
+                found.add(m.group(1))
+    assert found and found <= set(names), found - set(names)

@@ -6,7 +6,6 @@ mkdir -p gpurun_out/r6_b
 O=$PWD/gpurun_out/r6_b
 B="--no-cpu-baseline --no-profile --steps 12 --warmup 3"
 for r in 1 2; do
-  (cd _r4tree && timeout 300 python bench.py $B > $O/r4tree_$r.json 2> $O/r4tree_$r.err) || echo "r4tree $r failed"
   timeout 300 python bench.py $B --no-configs2 > $O/r6tree_$r.json 2> $O/r6tree_$r.err || echo "r6tree $r failed"
 done
 timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -k "temporal" > $O/test_temporal.log 2>&1; echo "temporal rc=$?"; tail -3 $O/test_temporal.log
