@@ -2,29 +2,34 @@
 """bench.py -- generated frames/sec of the Hallo denoising hot path on MI355X.
 
 Metric (BASELINE.json): generated frames/sec at 512x512, 16-frame window, 25 DDIM steps.
-Workload at every N (weak scaling): BASELINE.json configs[1] per GPU -- one clip = FaceAnimatePipeline.__call__
-on synthetic inputs already resident in HBM: face tokens + VAE-encode(3) + FaceLocator + ReferenceNet write
-+ 25 x (UNet3D, B=1, no CFG) + fused DDIM + batched VAE decode(16) + D2H of the fp32 frames; for N > 1 one
-RCCL all-gather of the decoded frames per wave of clips (BASELINE.json configs[3]'s exchange).
-A "step" = one clip per rank.  bf16 storage, fp32 accumulation, random-init weights of the reference
-architecture, synthetic inputs.  The K timed clips of a rank are independent (each carries its own reference / motion
-frames, the clip-parallel contract of DESIGN section 8) and are issued back to back over `--inflight` (default 3) pipeline
-objects + HIP streams sharing the weights, so that up to three clips overlap on the GPU (the 16x16 / 8x8 levels and the tail of
-every launch leave CUs idle that another clip's kernels fill), each pipeline with the kernel routing for that regime
-(FaceAnimatePipeline(routing="throughput") = hallo_amd.ops.THROUGHPUT_OPTIONS) and its own launch scratch.
+Workload at every N (weak scaling): BASELINE.json configs[1] per GPU -- one clip = FaceAnimatePipeline on synthetic inputs
+already resident in HBM: face tokens + VAE-encode(3) + FaceLocator + ReferenceNet write + 25 x (UNet3D, no CFG) + fused DDIM
++ batched VAE decode(16) + D2H of the fp32 frames; for N > 1 one RCCL all-gather of the decoded frames per group of clips
+(BASELINE.json configs[3]'s exchange).  A "step" = one clip per rank.  bf16 storage, fp32 accumulation, random-init weights of
+the reference architecture, synthetic inputs.
+The K timed clips of a rank are independent (each carries its own reference / motion frames, the clip-parallel contract of
+DESIGN section 8).  Round 6: they are evaluated FOUR AT A TIME (`--batch-clips`, default 4) through
+FaceAnimatePipeline.call_batch -- one denoising loop whose every UNet evaluation covers the 4 x 16 frames of a group (weights read
+once for four clips, 4 x the rows for the tiles of the 16x16 / 8x8 levels, no split-K there), every clip computed exactly as
+alone (own banks, tokens, masks, latents) -- on ONE pipeline / HIP stream (`--inflight`, default 1) with the kernel routing for
+that regime (hallo_amd.ops.BATCHED_OPTIONS).  Rounds 4-5 ran three one-clip pipelines in flight on three streams instead
+(`--batch-clips 1 --inflight 3`: 6.5 % slower on the same box, profiles/r6_batch_sweep.json).  A --steps that is not a multiple
+of the group size ends with one smaller group (its graph is captured in the warm-up too).
 `ms_per_step` = timed wall time / K (throughput); `clip_latency_ms` = that x clips in flight.
 
 Legs after the timed region (same process, same box), each one object on the JSON line:
-  inflight_identity    every rank: the first timed clips again, ALONE; the int64 sum of the frames' bit patterns must equal what the
-                       timed clip left behind while three clips overlapped, else the line carries "INVALID"
+  inflight_identity    every rank: the first timed groups again, ALONE (device idle before and after); the int64 sum of every clip's
+                       frames' bit patterns must equal what the timed clip left behind, else the line carries "INVALID"
   one_clip_at_a_time   rank 0, N = 1: three clips one after the other with the library-default routing (rounds 1-3 executed this way)
+  fp16                 rank 0, N = 1: the headline's execution and the one-clip execution with fp16 networks (the reference's own
+                       dtype, configs/inference/default.yaml:4)
   configs2             rank 0, N = 1: BASELINE.json configs[2] = the reference's default run (40 steps, CFG 3.5) as ONE video of 3
                        sequential clips through animate.video.generate_video, sequential and with cfg_split + overlap_decode
-  kernels / roofline / attention_families   rank 0: an instrumented eager clip, every operator launch bracketed by events on the
-                       launch stream, per kernel family and per kernel symbol
+  kernels / roofline / attention_families   rank 0: an instrumented eager group, every operator launch bracketed by events on the
+                       launch stream, per kernel family and per kernel symbol (per-clip numbers = the group's / clips per group)
   cpu_baseline         rank 0, N = 1: the CPU oracle on this box's host cores (child process, bounded)
 
-    python bench.py --gpus 1 --steps 2 --warmup 1
+    python bench.py --gpus 1 --steps 4 --warmup 4
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -428,8 +433,8 @@ def configs2_leg(pipe, audioproj, dev, S, Fr, n_clips, make_scheduler, dtype, va
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6, help="timed clips per rank")
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8, help="timed clips per rank")
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--ddim-steps", type=int, default=25)
@@ -440,13 +445,12 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds of host time the CPU baseline may use")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=None, help="A/B: hallo_set_option('gemm_variant', v) (default: library auto)")
-    ap.add_argument("--inflight", type=int, default=3,
-                    help="clips in flight per GPU: consecutive clips alternate over this many (pipeline object, HIP stream) pairs that share "
-                         "the weights, so that one clip's low-occupancy phases (16x16 / 8x8 levels, tails of every launch) are filled by "
-                         "another clip's kernels.  Throughput metric: the K timed clips are the same work, issued back to back.  Same box, "
-                         "same binary, library-default routing: 16.08 frames/s with 1, 17.7 with 2, 17.9 with 3 or 4, 17.6 with 6 "
-                         "(profiles/r4_inflight_ab.json); n > 1 also selects the throughput kernel routing (see --latency-routing)")
-    ap.add_argument("--batch-clips", type=int, default=1,
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="pipelines in flight per GPU: consecutive groups alternate over this many (pipeline object, HIP stream) pairs that share "
+                         "the weights.  With one clip per evaluation (--batch-clips 1) three of them recover the CUs one clip leaves idle "
+                         "(16.0 -> 17.6 frames/s, rounds 4-5); on top of a batch of four they add nothing (profiles/r6_batch_sweep.json).  "
+                         "n > 1 selects the throughput kernel routing (see --latency-routing)")
+    ap.add_argument("--batch-clips", type=int, default=4,
                     help="independent clips per UNet evaluation: a slot's unit of work is a GROUP of this many clips through "
                          "FaceAnimatePipeline.call_batch (one denoising loop over K x 16 frames: weights read once for K clips, K x the rows "
                          "for the tiles of the 16x16 / 8x8 levels, no split-K there); --steps that is not a multiple ends with one smaller group")
@@ -538,8 +542,11 @@ def main():
         # three clips in flight: the kernel routing for throughput (hallo_amd/ops.py THROUGHPUT_OPTIONS: +7 % over the one-clip routing
         # at --inflight 3, -4 % at --inflight 1) -- a property of the pipeline objects (FaceAnimatePipeline(routing=...)), applied
         # around their enqueue calls, not process state; --set-option overrides
+        # kernel routing of the timed pipelines: several pipelines in flight -> "throughput"; ONE pipeline evaluating a batch of clips ->
+        # "batched" (the one-clip routing + the fused 320-wide feed-forward); one clip at a time -> the library defaults
         thr_routing = (args.inflight > 1 or args.throughput_routing) and not args.latency_routing
-        routing = dict(_ops.THROUGHPUT_OPTIONS if thr_routing else _ops.LATENCY_OPTIONS)
+        routing_name = "throughput" if thr_routing else ("batched" if (args.batch_clips > 1 and args.guidance <= 1.0 and not args.latency_routing) else "latency")
+        routing = dict(_ops.ROUTINGS[routing_name])
         serial_routing = dict(_ops.LATENCY_OPTIONS)
         for kv in args.set_option:
             k_, v_ = kv.split("=")
@@ -577,7 +584,8 @@ def main():
     gather_u8 = world > 1 and (args.gather or ("f32" if dry else "u8")) == "u8"
     # rank 0 receives the whole wave (one clip per rank) and copies ALL of it to the host
     n_slots = 1 if dry else len(pipes)
-    KB = 1 if dry else max(1, args.batch_clips)          # clips per group (one UNet evaluation covers a group)
+    # clips per group (one UNet evaluation covers a group); a CFG evaluation is a batch of two already and cannot batch clips
+    KB = 1 if (dry or args.guidance > 1.0) else max(1, args.batch_clips)
     if gather_u8:
         hosts = [torch.empty((world if rank == 0 else 1, KB * Fr, S * S, 3), dtype=torch.uint8) for _ in range(n_slots)]
     else:
@@ -766,7 +774,7 @@ def main():
                    "options": args.set_option or None,
                    "scratch": ("ONE launch scratch shared by all pipelines in flight (racy: timing A/B only)" if args.shared_scratch else "own per pipeline")
                               + (", split-K slab %d MB" % args.scratch_mb if args.scratch_mb is not None else ""),
-                   "kernel_routing": ("dry run" if dry else ("throughput: " if thr_routing else "library defaults: ") + str(routing)),
+                   "kernel_routing": ("dry run" if dry else routing_name + ": " + str(routing)),
                    "clips_in_flight_per_gpu": n_slots * KB, "pipelines_in_flight_per_gpu": n_slots, "clips_per_unet_evaluation": KB,
                    "warmup_clips_run": sum(len(g_) for _, g_ in warm),
                    "clips_per_step": world, "parallelism": f"clip-parallel x{world}" + (

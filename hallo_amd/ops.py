@@ -84,7 +84,12 @@ def options_fingerprint():
 #   split_k_max = 4  split-K factors capped at 4 (8-16 alone): half the slab traffic, fewer but longer workgroups             +0.6 %
 THROUGHPUT_OPTIONS = {"gemm_rs": 0, "ff_fused": 1, "gn_fused": 0, "gemm4": 0, "split_k_max": 4}
 LATENCY_OPTIONS = {"gemm_rs": 2, "ff_fused": 0, "gn_fused": 1, "gemm4": 1, "split_k_max": 16}          # the library defaults
-ROUTINGS = {"throughput": THROUGHPUT_OPTIONS, "latency": LATENCY_OPTIONS}
+# Kernel routing for a BATCH of independent clips through one evaluation (FaceAnimatePipeline.call_batch, bench.py --batch-clips; round
+# 6): one in-order stream whose launches carry K x the rows, so the lowest-latency kernels win as they do for one clip (the row-
+# stationary K = 320 / 640 GEMMs: +7 % over gemm_rs = 0 at K = 4) -- except that the fused 320-wide feed-forward now has the rows to
+# fill the chip several times over and its third of the HBM bytes pays (+0.4 %); alternating runs on one box, profiles/r6_batch_sweep.json.
+BATCHED_OPTIONS = dict(LATENCY_OPTIONS, ff_fused=1)
+ROUTINGS = {"throughput": THROUGHPUT_OPTIONS, "latency": LATENCY_OPTIONS, "batched": BATCHED_OPTIONS}
 
 
 class routing:

@@ -30,8 +30,9 @@ def test_full_size_bodies_replay(Fz, dtype):
     Fz.test_full_pipeline_trajectory(dtype, "pipeline40cfg", "latency+cfg_split", rep)     # round 5: the two-halves form of the CFG trajectory
     if dtype == torch.bfloat16:                # round 5: the in-flight identity test's "alone" half (inputs, routing attribute, scratch scope)
         Fz.test_clips_in_flight_identity_at_the_benchmarked_configuration(rep)
+    Fz.test_call_batch_trajectory(dtype, rep)        # round 6: four clips per evaluation, the stored-trajectory clip in batch position 2
     Fz.test_zz_release_cache(rep)
-    assert len(rep) == 1 + len(Fz.CASES) + 2 + 2 + 3 * len(Fz.TRAJ) + 3 and all(r["arch"] == "small" for r in rep)
+    assert len(rep) == 1 + len(Fz.CASES) + 2 + 2 + 3 * len(Fz.TRAJ) + 3 + 2 and all(r["arch"] == "small" for r in rep)
 
 
 def test_round_both_is_exact_in_both_types():

@@ -598,6 +598,72 @@ def test_full_pipeline_trajectory(dtype, name, routing, report):
         assert p16 >= 35.0 and (ARCH != "full" or within1 >= (0.99 if dtype == torch.float16 else 0.90))
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_call_batch_trajectory(dtype, report):
+    """FaceAnimatePipeline.call_batch at the benchmarked configuration (round 6; bench.py --batch-clips 4, routing "batched", hipGraph
+    replay): FOUR independent clips through one denoising loop (64 frames per UNet evaluation; hallo/models/unet_3d.py:510-527 takes
+    any batch, hallo/animate/face_animate.py:397-417 batches two evaluations itself).  Clip 2 of the batch is the clip whose fp32
+    oracle trajectory is stored (pipeline25: 512 x 512 x 16 frames x 25 steps, no CFG): its latents after EVERY step and its frames
+    must match the oracle's as the one-clip run's do -- the other three clips (other reference images, audio, masks, latents) must
+    not leak into it through the banks, the face / audio tokens or the motion-frame rows -- and the whole batch is run twice, the
+    second time entirely from the captured graph's addresses (clips permuted), byte-identical per clip."""
+    from oracle import harness as Hn
+    from hallo_amd.animate.face_animate import FaceAnimatePipeline
+    from hallo_amd.scheduler import DDIMScheduler
+    name, K, slot = "pipeline25", 4, 2
+    c = _traj_cfg(name)
+    d, args, lat, _ = _traj_inputs(name)
+    ref = _traj_oracle(name)
+    n = _native(dtype)
+    kwa, _ = _arch()
+    S, Fr, steps = c["S"], c["Fr"], c["steps"]
+    keys = ("ref_image", "face_emb", "audio_tensor", "face_mask", "pixel_values_full_mask", "pixel_values_face_mask", "pixel_values_lip_mask")
+    gold = dict(zip(keys, args[:7]), latents=lat)
+
+    def other(i):
+        o_ = Hn.clip_inputs(S, Fr, audio_dim=kwa["audio_dim"], seed=7000 + i)
+        o_["latents"] = torch.randn(o_["latents"].shape, generator=torch.Generator().manual_seed(7100 + i))
+        a_ = (_rb(o_["ref_image"]), _rb(o_["face_emb"]), _rb(o_["audio"]), torch.roll(o_["face_mask"], shifts=16 * (i + 1), dims=-1),
+              [_rb(m) for m in o_["full"]], [_rb(m) for m in o_["face"]], [_rb(m) for m in o_["lip"]])
+        return dict(zip(keys, a_), latents=_rb(o_["latents"]))
+    clips = [other(0), other(1), gold, other(2)]
+    assert len(clips) == K and clips[slot] is gold
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="linear", clip_sample=False, steps_offset=1,
+                          prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+    graph = DEV != "cpu"
+    pipe = FaceAnimatePipeline(vae=n["vae"], reference_unet=n["reference_unet"], denoising_unet=n["denoising_unet"],
+                               face_locator=n["face_locator"], image_proj=n["imageproj"], scheduler=sched, use_graph=graph, routing="batched")
+    seen = []
+    try:
+        outs = pipe.call_batch(clips, S, S, Fr, steps, c["gs"], motion_scale=d["motion_scale"],
+                               callback=lambda i, t, l: seen.append((int(t), l[slot:slot + 1].float().cpu() if i + 1 in c["keep"] else None)))
+        perm = [2, 0, 3, 1]                                  # second batch: same clips, other batch positions, all steps 1.. replayed
+        outs2 = pipe.call_batch([clips[j] for j in perm], S, S, Fr, steps, c["gs"], motion_scale=d["motion_scale"])
+        if graph:
+            (sg,) = pipe._graphs.values()
+            assert sg.graph is not None and sg.replays == 2 * (steps - 1)
+    finally:
+        pipe.reset_graphs()
+    assert [t for t, _ in seen] == [int(t) for t in ref["timesteps"]] and len(seen) == steps
+    kept = [l for _, l in seen if l is not None]
+    per_step = [Hn.rel_l2(a, b) for a, b in zip(kept, ref["latents"])]
+    per_step_max = [float((a.float() - b.float()).abs().max() / b.float().pow(2).mean().sqrt()) for a, b in zip(kept, ref["latents"])]
+    _rec(report, f"full_call_batch_latents[K={K},{S}x{S}x{Fr}f,{steps} steps]", dtype, max(per_step), 5e-2,
+         per_step=[round(v, 6) for v in per_step], max_abs_over_rms=[round(v, 5) for v in per_step_max], oracle=ref["oracle"],
+         launch="hipGraph replay" if graph else "eager", kernel_routing="batched", batch_position=slot)
+    assert max(per_step) <= 5e-2 and max(per_step_max) <= 0.5, (per_step, per_step_max)
+    vid = outs[slot].videos
+    p = Hn.psnr(vid[:, :, c["frames"]], ref["video"])
+    same = all(torch.equal(outs2[perm.index(j)].videos, outs[j].videos) for j in range(K))
+    differ = min(Hn.psnr(outs[slot].videos, outs[j].videos) for j in range(K) if j != slot)
+    report.append({"test": f"full_call_batch_frames[K={K},{S}x{S}x{Fr}f,{steps} steps]", "dtype": str(dtype), "arch": ARCH, "psnr_db": p,
+                   "tol_psnr_db": 35.0, "permuted_batch_byte_identical": same, "psnr_db_to_the_nearest_other_clip": differ})
+    print("call_batch PSNR", p, "permuted identical", same, "nearest other clip", differ)
+    assert p >= 35.0 and differ < 30.0
+    # a clip's result does not depend on its batch position or neighbours (row-wise / per-frame / per-clip kernels, fixed-order sums)
+    assert same
+
+
 def test_clips_in_flight_identity_at_the_benchmarked_configuration(report):
     """The configuration that produces bench.py's headline: 512 x 512 x 16 frames x 25 DDIM
     steps, full width, bf16, THREE pipelines in flight on three HIP streams sharing the networks, throughput kernel routing
