@@ -94,11 +94,11 @@ class OpProfiler:
         dt = "__bf16" if self.dtype == torch.bfloat16 else "_Float16"
         if name in ("gemm", "conv3x3"):
             c = ops.get_option("last_gemm_kernel")
-            lnf, kern, mode, sub = c // 1000, (c // 100) % 10, (c // 10) % 10, c % 10
+            emit, lnf, kern, mode, sub = c // 10000, (c // 1000) % 10, (c // 100) % 10, (c // 10) % 10, c % 10
             if kern == 1:
                 return "gemm_kernel<%s,%s,%s>" % (dt, "true" if mode == 1 else "false", "true" if mode == 2 else "false")
             if kern == 2:
-                return "gemm2_kernel<%s,%d,%d,%d>" % (dt, mode, sub, lnf)
+                return "gemm2_kernel<%s,%d,%d,%d,%d>" % (dt, mode, sub, lnf, emit)      # <T, MODE, STAGES, LNF, EMIT>: as rocprofv3 prints it
             if kern == 4:      # row-stationary kernel (csrc/gemm_rs.hip): <T, K/16, W blocks per chunk, geglu, layernorm>
                 return "gemm_rs_kernel<%s,%d,%d,%s,%s>" % (dt, 20 if sub == 1 else 40, 4 if sub == 1 else 2,
                                                            "true" if mode == 2 else "false", "true" if lnf else "false")
@@ -585,7 +585,7 @@ def main():
     # rank 0 receives the whole wave (one clip per rank) and copies ALL of it to the host
     n_slots = 1 if dry else len(pipes)
     # clips per group (one UNet evaluation covers a group); a CFG evaluation is a batch of two already and cannot batch clips
-    KB = 1 if (dry or args.guidance > 1.0) else max(1, args.batch_clips)
+    KB = 1 if args.guidance > 1.0 else max(1, args.batch_clips)
     if gather_u8:
         hosts = [torch.empty((world if rank == 0 else 1, KB * Fr, S * S, 3), dtype=torch.uint8) for _ in range(n_slots)]
     else:
@@ -637,7 +637,7 @@ def main():
         kb = len(grp)
         audioproj = ap if ap is not None else audioproj_main
         if dry:
-            frames = torch.full((Fr, 3, S * S), grp[0]["stub"])
+            frames = torch.cat([torch.full((Fr, 3, S * S), g_["stub"]) for g_ in grp])
         else:
             h = S // 8
             if kb == 1:
@@ -930,7 +930,7 @@ def main():
         # something this run produced (the counter passes cannot run inside a timed bench).
         traffic = None
         try:
-            tpath = next(pp for pp in (os.path.join(ROOT, "profiles", f) for f in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json")) if os.path.exists(pp))
+            tpath = next(pp for pp in (os.path.join(ROOT, "profiles", f) for f in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json")) if os.path.exists(pp))
             tj = json.load(open(tpath))
             t = tj.get(name.split("<")[0])
             if t:

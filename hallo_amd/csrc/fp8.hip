@@ -14,6 +14,7 @@
 // stream and the L2 -> LDS fabric, so the A/B is roughly neutral; the path exists because the north
 // star names it, with its parity measured (tests/test_fp8_gpu.py, profiles/r2_fp8_ab.json).
 #include "common.h"
+#include <string.h>
 #include "../../include/hallo_amd.h"
 
 namespace hallo {
@@ -113,7 +114,14 @@ struct Fp8GemmArgs {
   int tiles_n;
 };
 
-template <typename T>
+// MX (round 6): the contraction on `v_mfma_scale_f32_32x32x64_f8f6f4` -- the block-scaled OCP-MX form, the only fp8 MFMA of gfx950 that runs
+// at the fp8 rate (2 x bf16; the non-scaled 32x32x16 form has the bf16 K per instruction and the bf16 rate) -- with UNIT block scales
+// (E8M0 127 = 2^0 in every scale byte): the operands stay plain per-row / per-channel-scaled e4m3 and the per-row x per-channel
+// scales are applied to the fp32 accumulators in the epilogue exactly as before.  One instruction contracts the whole 64-byte K step
+// of a 32 x 32 block: a lane hands over 32 consecutive bytes of its row (k half = lane / 32), read as two 16-byte LDS pieces through
+// the same chunk swizzle.  The k order inside an instruction is the same function of (lane, byte) for both operands, so the sum is
+// the same set of exact products in another order: results agree with the 32x32x16 form to fp32 summation noise.
+template <typename T, bool MX>
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs p) {
   constexpr int BM = 128, BN = 128, BK = 64;
   constexpr int TILE = BM * BK;                                 // bytes per operand stage
@@ -171,8 +179,29 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs p) {
   const lds_u8* const fa = lds + (wm * 64 + l31) * BK + hi * 8;
   const lds_u8* const fb = lds + TILE + (wn * 64 + l31) * BK + hi * 8;
   typedef const __attribute__((address_space(3))) long* ldsl;
+  typedef __attribute__((ext_vector_type(4))) int intx4;
+  typedef __attribute__((ext_vector_type(8))) int intx8;
+  typedef const __attribute__((address_space(3))) intx4* ldsq;
+  // MX fragments: the 32 bytes k = 32 hi .. 32 hi + 31 of row (base + l31) = logical 16-byte chunks 2 hi, 2 hi + 1
+  const lds_u8* const fa32 = lds + (wm * 64 + l31) * BK;
+  const lds_u8* const fb32 = lds + TILE + (wn * 64 + l31) * BK;
+  const int c0 = ((2 * hi) ^ sw) * 16, c1 = ((2 * hi + 1) ^ sw) * 16;
+  auto frag32 = [&](const lds_u8* base) {
+    const intx4 lo = *(ldsq)(base + c0), hi4 = *(ldsq)(base + c1);
+    return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
   auto compute = [&](int buf) {
     const int bo = buf * 2 * TILE;
+    if (MX) {
+      constexpr int UNIT = 0x7F7F7F7F;       // E8M0 scale bytes: 2^(127 - 127) = 1 for every 32-element block
+      const intx8 a0 = frag32(fa32 + bo), a1 = frag32(fa32 + bo + 32 * BK);
+      const intx8 w0 = frag32(fb32 + bo), w1 = frag32(fb32 + bo + 32 * BK);
+      acc[0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w0, a0, acc[0][0], 0, 0, 0, UNIT, 0, UNIT);
+      acc[0][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w0, a1, acc[0][1], 0, 0, 0, UNIT, 0, UNIT);
+      acc[1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w1, a0, acc[1][0], 0, 0, 0, UNIT, 0, UNIT);
+      acc[1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w1, a1, acc[1][1], 0, 0, 0, UNIT, 0, UNIT);
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int co = (ks ^ sw) * 16;
@@ -242,6 +271,16 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs p) {
 
 using namespace hallo;
 
+static int g_fp8_mx = 1;
+extern "C" int hallo_set_option_fp8(const char* name, int value) {
+  if (name && !strcmp(name, "fp8_mx")) { if (value < 0 || value > 1) return -22; g_fp8_mx = value; return 0; }
+  return -22;
+}
+extern "C" int hallo_get_option_fp8(const char* name) {
+  if (name && !strcmp(name, "fp8_mx")) return g_fp8_mx;
+  return -22;
+}
+
 extern "C" int hallo_quant_rows_fp8(const void* x, int64_t ldx, void* q, float* scale, int64_t rows, int C, const void* gamma,
                                     const void* beta, float eps, int dtype, void* stream) {
   if (!x || !q || !scale || rows <= 0 || C <= 0 || (C & 7) || C > 1536 || ldx < C || (ldx & 7)) return -22;
@@ -277,8 +316,11 @@ extern "C" int hallo_gemm_fp8(const hallo_gemm_fp8_desc* d, void* stream) {
   a.tiles_n = (d->N + 127) / 128;
   const int tiles = ((d->M + 127) / 128) * a.tiles_n;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (d->dtype == DT_F16) hipLaunchKernelGGL((gemm_fp8_kernel<_Float16>), dim3(tiles), dim3(256), 0, st, a);
-  else if (d->dtype == DT_BF16) hipLaunchKernelGGL((gemm_fp8_kernel<__bf16>), dim3(tiles), dim3(256), 0, st, a);
+  // hallo_set_option("fp8_mx", 1 (default) | 0): the MX-rate contraction (unit block scales) or the non-scaled 32x32x16 form (A/B)
+  if (d->dtype == DT_F16) { if (g_fp8_mx) hipLaunchKernelGGL((gemm_fp8_kernel<_Float16, true>), dim3(tiles), dim3(256), 0, st, a);
+                            else hipLaunchKernelGGL((gemm_fp8_kernel<_Float16, false>), dim3(tiles), dim3(256), 0, st, a); }
+  else if (d->dtype == DT_BF16) { if (g_fp8_mx) hipLaunchKernelGGL((gemm_fp8_kernel<__bf16, true>), dim3(tiles), dim3(256), 0, st, a);
+                                  else hipLaunchKernelGGL((gemm_fp8_kernel<__bf16, false>), dim3(tiles), dim3(256), 0, st, a); }
   else return -22;
   HALLO_CHECK_LAUNCH();
   return 0;

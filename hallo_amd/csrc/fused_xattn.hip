@@ -353,10 +353,12 @@ extern "C" int hallo_set_option_xattn(const char* name, int value) {
   return -2;
 }
 
+extern "C" int hallo_get_option_fp8(const char* name);
+
 extern "C" int hallo_get_option_xattn(const char* name) {
   if (name && !strcmp(name, "xattn_tiled")) return g_xattn_tiled;
   if (name && !strcmp(name, "xattn_cap")) return g_xattn_cap;
-  return -22;
+  return hallo_get_option_fp8(name);       // fp8.hip
 }
 
 extern "C" int hallo_row_stats(const void* x, float* stats, int64_t rows, int C, float eps, int dtype, void* stream);   // norm_elementwise.hip

@@ -45,7 +45,7 @@ int hallo_abi_version(void);
 int hallo_set_option(const char* name, int value);
 /* Read an option back; "last_gemm_kernel" = the kernel the last hallo_gemm / hallo_conv3x3_nhwc call launched, as
  * 1000 * f + 100 * k + 10 * mode + s: k = 1 gemm_kernel / 2 gemm2_kernel / 3 gemm3_kernel, mode = 0 gemm / 1 conv3x3 /
- * 2 geglu, s = LDS stages (gemm2) or TM (gemm3), f = fused-LayerNorm form of gemm2 (0 / 1 / 2).  Used by bench.py to report achieved rates per kernel SYMBOL.  -22 = unknown. */
+ * 2 geglu, s = LDS stages (gemm2) or TM (gemm3), f = fused-LayerNorm form of gemm2 (0 / 1 / 2); + 10000 * e, e = row_parts epilogue form of gemm2 (0 / 1 / 2).  Used by bench.py to report achieved rates per kernel SYMBOL.  -22 = unknown. */
 int hallo_get_option(const char* name);
 /* ABI v8: the names of every option hallo_set_option accepts, comma-separated (static storage).  A host that caches launch
  * sequences (hipGraphs of a UNet evaluation) keys them on the VALUES of all of these. */

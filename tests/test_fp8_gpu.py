@@ -68,6 +68,19 @@ def test_gemm_fp8(dtype, M, N, K, report):
                    "tol_vs_16bit": 5e-2})
     assert e1 < (2e-3 if dtype == torch.float16 else 1e-2), e1
     assert e2 < 5e-2, e2
+    # round 6: the default contraction is the MX-rate form (v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales); the non-scaled
+    # 32x32x16 form (fp8_mx = 0) sums the same exact products in another order: the two agree to fp32 summation noise, i.e. to
+    # (almost always) the same rounded 16-bit outputs
+    assert ops.get_option("fp8_mx") == 1
+    ops.set_option("fp8_mx", 0)
+    try:
+        out0 = ops.gemm_fp8(aq, sa, wq, sw, dtype, b, residual=res, lead_cols=lead, lead_alpha=0.25)
+    finally:
+        ops.set_option("fp8_mx", 1)
+    e3 = ((out.float() - out0.float()).norm() / out0.float().norm()).item()
+    same = (out == out0).float().mean().item()
+    report.append({"test": f"gemm_fp8_mx_vs_nonscaled[{M},{N},{K}]", "dtype": str(dtype), "rel_l2": e3, "outputs_equal": same})
+    assert e3 < (3e-4 if dtype == torch.float16 else 2e-3) and same > 0.98, (e3, same)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["fp16", "bf16"])

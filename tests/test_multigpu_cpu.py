@@ -63,7 +63,7 @@ def test_bench_control_flow_world2(tmp_path):
     port = 29600 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--dry-run-cpu", "--size", "16", "--frames", "4"]
+           "--dry-run-cpu", "--size", "16", "--frames", "4", "--batch-clips", "1"]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -77,6 +77,25 @@ def test_bench_control_flow_world2(tmp_path):
     assert abs(out["value"] - 2 * 3 * 4 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
 
 
+def test_bench_control_flow_world2_groups_of_clips():
+    """Round 6: the default execution evaluates GROUPS of clips (--batch-clips): with 2 ranks, 3 timed clips per rank in groups of
+    2 the timed region is a group of 2 and a remainder group of 1, each followed by ONE all-gather of the group's frames
+    ([world, clips x frames, ...]); the warm-up runs a group of every size the timed region will see."""
+    import json
+    import subprocess
+    port = 29700 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--dry-run-cpu", "--size", "16", "--frames", "4", "--batch-clips", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["config"]["clips_per_unet_evaluation"] == 2
+    # the last timed group (one clip: index warmup + 2 = 4) as rank 0 received it, first frame of each rank's block
+    assert out["dry_run_wave"] == [4.0, 1004.0]
+    assert abs(out["value"] - 2 * 3 * 4 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+
+
 def test_bench_self_spawns_without_a_launcher():
     """`python bench.py --gpus 2` with WORLD_SIZE unset: bench.py re-executes itself through
     torch.distributed.run with one rank per GPU instead of dying on the world-size check; one JSON line, n_gpus 2."""
@@ -85,7 +104,7 @@ def test_bench_self_spawns_without_a_launcher():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run-cpu",
-                        "--size", "16", "--frames", "4"], capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+                        "--size", "16", "--frames", "4", "--batch-clips", "1"], capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -97,7 +116,7 @@ def test_bench_self_spawns_without_a_launcher():
 def test_bench_control_flow_world1():
     import json
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-cpu", "--size", "16", "--frames", "4"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-cpu", "--size", "16", "--frames", "4", "--batch-clips", "1"],
                        capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])

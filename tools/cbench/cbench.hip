@@ -170,7 +170,8 @@ static hallo_attn_desc attn_desc(const uint16_t* qkv, const uint16_t* bkv, uint1
   d.batch = B; d.heads = H; d.head_dim = HD; d.Lq = L; d.Lkv1 = L;
   d.q_bs = d.k1_bs = d.v1_bs = (long)L * 3 * C; d.q_rs = d.k1_rs = d.v1_rs = 3 * C;
   d.o_bs = (long)L * C; d.o_rs = C;
-  if (bank) { d.k2 = bkv; d.v2 = bkv + C; d.Lkv2 = L; d.k2_bs = d.v2_bs = (long)L * 2 * C; d.k2_rs = d.v2_rs = 2 * C; d.kv2_batch_div = B; }
+  // bank = number of reference banks (clips in the batch): frame row b reads bank b / (B / bank) -- one clip: every row bank 0
+  if (bank) { d.k2 = bkv; d.v2 = bkv + C; d.Lkv2 = L; d.k2_bs = d.v2_bs = (long)L * 2 * C; d.k2_rs = d.v2_rs = 2 * C; d.kv2_batch_div = B / bank; }
   else d.kv2_batch_div = 1;
   d.kv2_batch_mod = 0; d.kv2_first_batch = 0;
   d.scale = 1.0f / sqrtf((float)HD); d.dtype = dt; d.q_prescaled = 1;
@@ -185,7 +186,7 @@ static int cmd_attn_det(int argc, char** argv) {
   int bad = 0;
   for (int dt = 0; dt < 2; ++dt)
     for (const AttnCase& c : cases) {
-      const long nq = (long)c.B * c.L * 3 * C, nb = (long)c.L * 2 * C, no = (long)c.B * c.L * C;
+      const long nq = (long)c.B * c.L * 3 * C, nb = (long)(c.bank ? c.bank : 1) * c.L * 2 * C, no = (long)c.B * c.L * C;
       uint16_t* qkv = dalloc<uint16_t>(nq); uint16_t* bkv = dalloc<uint16_t>(nb); uint16_t* o = dalloc<uint16_t>(no);
       float* ref = dalloc<float>(no);
       const bool first = (&c == &cases[0]);
@@ -244,13 +245,15 @@ static int cmd_attn_time(int argc, char** argv) {
   if (argc > 0) { variants.clear(); for (char* t = strtok(argv[0], ","); t; t = strtok(nullptr, ",")) variants.push_back(atoi(t)); }
   const int H = 8, HD = 40, C = H * HD;
   const AttnCase cases[] = {{"L0 self+bank 16x4096x(4096+4096)", 16, 4096, 1}, {"L0 audio-block self 16x4096x4096", 16, 4096, 0},
-                            {"256^2 L0 self+bank 8x1024x(1024+1024)", 8, 1024, 1}};
+                            {"256^2 L0 self+bank 8x1024x(1024+1024)", 8, 1024, 1},
+                            // round 6: a batch of four clips through one evaluation (FaceAnimatePipeline.call_batch): 64 frame rows, 4 banks
+                            {"L0 self+bank, 4 clips: 64x4096x(4096+4096)", 64, 4096, 4}, {"L0 audio-block self, 4 clips: 64x4096x4096", 64, 4096, 0}};
   Timer tm;
-  const char* only_case = getenv("CBENCH_CASE");      // PMC passes: one shape (0..2), bf16 only
+  const char* only_case = getenv("CBENCH_CASE");      // PMC passes: one shape (0..4), bf16 only
   for (int dt = 1; dt >= 0; --dt)
     for (const AttnCase& c : cases) {
       if (only_case && (dt != 1 || (int)(&c - cases) != atoi(only_case))) continue;
-      const long nq = (long)c.B * c.L * 3 * C, nb = (long)c.L * 2 * C, no = (long)c.B * c.L * C;
+      const long nq = (long)c.B * c.L * 3 * C, nb = (long)(c.bank ? c.bank : 1) * c.L * 2 * C, no = (long)c.B * c.L * C;
       uint16_t* qkv = dalloc<uint16_t>(nq); uint16_t* bkv = dalloc<uint16_t>(nb); uint16_t* o = dalloc<uint16_t>(no);
       fill(qkv, nq, 11 + dt, 1.0f, 0.0f, dt); fill(bkv, nb, 23 + dt, 1.0f, 0.0f, dt);
       uint16_t* tmp = dalloc<uint16_t>(nq); fill(tmp, nq, 77 + dt, 0.2281f, 0.0f, dt);

@@ -3,7 +3,7 @@
 bytes are quoted next to them, one launch shape per rocprofv3 pass (tools/cbench/pmc.sh, CBENCH_CASE selects the attention
 shape; separate passes per counter group, --kernel-trace only).
 
-    for c in 0 1; do CBENCH_CASE=$c PMC_GROUPS="fetch write hit" tools/cbench/pmc.sh a40_c$c attn-time 1; done
+    for c in 0 1 3 4; do CBENCH_CASE=$c PMC_GROUPS="fetch write hit" tools/cbench/pmc.sh a40_c$c attn-time 1; done
     PMC_GROUPS="fetch write hit" tools/cbench/pmc.sh rs2_qkv gemm 65536 960 320 ln nocheck      (rs2_geglu: ... 1280 320 geglu ln)
     python tools/pmc_traffic_cbench.py gpurun_out > profiles/r2_pmc_traffic.json
 
@@ -55,7 +55,12 @@ res = {
         entry("a40_c0", "attn40_kernel", "L0 spatial self-attention, K/V = [self 4096 ; reference bank 4096], 16 frames x 8 heads x "
               "4096 queries, hd 40 (125 launches per 25-step clip)", 3 * qkv_o + bank, qkv_o),
         entry("a40_c1", "attn40_kernel", "L0 audio-block self-attention, K/V = self 4096, same q geometry (125 launches per clip)",
-              3 * qkv_o, qkv_o)) if e],
+              3 * qkv_o, qkv_o),
+        # round 6: four clips per evaluation (bench.py --batch-clips 4): 64 frame rows, one bank per clip
+        entry("a40_c3", "attn40_kernel", "L0 spatial self-attention of a batch of 4 clips, K/V = [self 4096 ; the clip's reference bank 4096], 64 frames x 8 heads "
+              "x 4096 queries, hd 40 (125 launches per 25-step group of 4 clips)", 4 * (3 * qkv_o + bank), 4 * qkv_o),
+        entry("a40_c4", "attn40_kernel", "L0 audio-block self-attention of a batch of 4 clips, K/V = self 4096 (125 launches per group)",
+              4 * 3 * qkv_o, 4 * qkv_o)) if e],
     "gemm_rs2_kernel": [e for e in (
         entry("rs2_qkv", "gemm_rs2_kernel", "fused q|k|v projection with LayerNorm, 65536 x 960 x 320",
               es * (M * 320 + 960 * 320), es * M * 960),
