@@ -380,8 +380,10 @@ def cpu_baseline(frames, steps_ddim, budget_s=150.0):
 
 # (the throughput kernel routing loses with TWO evaluations in flight: 5.87 against 6.03, and taken one option at a time only the row-
 # stationary GEMMs matter -- gemm_rs = 0 costs 5 %; decode overlap alone is worth +-0: profiles/r5_configs2_ab.json, tools/r5_configs2_ab.py)
+# round 6 (profiles/r6_configs2_ab.json, two alternating rounds on one box): sequential 5.80 / 5.80, the same with the "batched" routing 5.75 / 5.76,
+# overlapped 5.93 / 5.43, overlapped + "batched" routing (the fused 320-wide feed-forward for the two B = 1 halves) 6.01 / 5.99
 CONFIGS2_VARIANTS = (("sequential", dict(routing="latency"), {}),
-                     ("overlapped", dict(routing="latency", cfg_split=True), dict(overlap_decode=True)))
+                     ("overlapped", dict(routing="batched", cfg_split=True), dict(overlap_decode=True)))
 
 
 def configs2_leg(pipe, audioproj, dev, S, Fr, n_clips, make_scheduler, dtype, variants=CONFIGS2_VARIANTS):
