@@ -466,6 +466,9 @@ def main():
     ap.add_argument("--no-slot-wait", action="store_true", help="A/B: do not wait (blocking event) for a slot's previous clip before enqueuing its next one")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: hallo_set_option(NAME, VALUE) before the pipeline is built (e.g. gemm4=0); recorded in config.options")
+    ap.add_argument("--materialize-skip-concat", action="store_true",
+                    help="A/B: write the [x | skip] channel concatenation in front of the up-block resnets (two copy2d launches each, rounds 1-5) "
+                         "instead of reading both tensors in place (hallo_groupnorm_nhwc2 + split 1x1 shortcut, round 6)")
     ap.add_argument("--shared-scratch", action="store_true",
                     help="A/B, TIMING ONLY: every pipeline in flight uses ONE launch scratch (round 4's racy execution: frames are wrong, "
                          "inflight_identity reports it); isolates what own split-K slabs / GroupNorm scratch cost (VERDICT r5 item 1)")
@@ -553,6 +556,9 @@ def main():
         for kv in args.set_option:
             k_, v_ = kv.split("=")
             routing[k_] = serial_routing[k_] = int(v_)
+        if args.materialize_skip_concat:
+            import hallo_amd.models.resnet as _rn
+            _rn.SKIP_CONCAT_IN_PLACE = False
         if args.scratch_mb is not None:
             _ops.SPLITK_WS_BYTES = int(args.scratch_mb) << 20
         from hallo_amd.synthetic import build_pipeline, clip_inputs

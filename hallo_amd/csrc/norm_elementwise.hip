@@ -14,8 +14,20 @@ namespace hallo {
 // ------------------------------------------------------------------------------------------
 constexpr int GN_MAX_GROUPS = 32;
 
+// Two-source input (round 6): the C channels of a row are the C1 channels of x followed by the C - C1 channels of x2 -- the skip
+// concatenation `torch.cat([hidden_states, res_hidden_states], dim=1)` in front of an up-block resnet (hallo/models/unet_3d_blocks.py:
+// 1131,1373) read in place instead of materialised.  A thread owns whole 8-channel vector columns and C1 % 8 == 0, so a column lies in one
+// source: its base pointer and row pitch are picked once.  x2 == nullptr / C1 == C: one source.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ ws,
+struct GnSrc { const T* base; long pitch; };
+template <typename T>
+__device__ __forceinline__ GnSrc<T> gn_src(const T* x, const T* x2, int C, int C1, long img_rows, int c0) {
+  if (c0 < C1) return {x + img_rows * C1 + c0, (long)C1};
+  return {x2 + img_rows * (C - C1) + (c0 - C1), (long)(C - C1)};
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, float* __restrict__ ws,
                                                        int HW, int C, int groups, int rows_per_chunk) {
   using V8 = typename Vec<T>::v8;
   // Deterministic block reduction (no float atomics: results are bit-reproducible run to run).  A thread owns at most
@@ -41,14 +53,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
       float a[8], q[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { a[e] = 0.0f; q[e] = 0.0f; }
-      const T* base = x + ((long)img * HW) * C + v * 8;
+      const GnSrc<T> src = gn_src<T>(x, x2, C, C1, (long)img * HW, v * 8);
+      const T* base = src.base;
+      const long P = src.pitch;
       int r = r_begin + my_row;
       // 4 independent 16-byte loads in flight per thread (the loop is latency-bound otherwise)
       for (; r + 3 * row_lanes < r_end; r += 4 * row_lanes) {
-        V8 v0 = ld8<T>(base + (long)r * C);
-        V8 v1 = ld8<T>(base + (long)(r + row_lanes) * C);
-        V8 v2 = ld8<T>(base + (long)(r + 2 * row_lanes) * C);
-        V8 v3 = ld8<T>(base + (long)(r + 3 * row_lanes) * C);
+        V8 v0 = ld8<T>(base + (long)r * P);
+        V8 v1 = ld8<T>(base + (long)(r + row_lanes) * P);
+        V8 v2 = ld8<T>(base + (long)(r + 2 * row_lanes) * P);
+        V8 v3 = ld8<T>(base + (long)(r + 3 * row_lanes) * P);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float f0 = to_f32(v0[e]), f1 = to_f32(v1[e]), f2 = to_f32(v2[e]), f3 = to_f32(v3[e]);
@@ -57,7 +71,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         }
       }
       for (; r < r_end; r += row_lanes) {
-        V8 val = ld8<T>(base + (long)r * C);
+        V8 val = ld8<T>(base + (long)r * P);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float f = to_f32(val[e]); a[e] += f; q[e] += f * f; }
       }
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 
 // GroupNorm, pass 2: finalise the statistics (fp64 combine) and apply scale/shift (+SiLU).
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, T* __restrict__ y,
                                                        const T* __restrict__ gamma, const T* __restrict__ beta,
                                                        const float* __restrict__ ws, int HW, int C, int groups,
                                                        int nchunks, int rows_per_block, float eps, int silu) {
@@ -169,10 +183,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         sc[e] = s_rstd[g] * to_f32(g8[e]);
         sh[e] = to_f32(b8[e]) - s_mean[g] * sc[e];
       }
-      const T* xb = x + ((long)img * HW) * C + c0;
+      const GnSrc<T> src = gn_src<T>(x, x2, C, C1, (long)img * HW, c0);
+      const T* xb = src.base;
       T* yb = y + ((long)img * HW) * C + c0;
       for (long r = r_begin + my_row; r < r_end; r += row_lanes) {
-        V8 val = ld8<T>(xb + r * C);
+        V8 val = ld8<T>(xb + r * src.pitch);
         V8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 // on one XCD (xcd_remap) so that the 128-byte lines shared by neighbouring slices are fetched once.
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, T* __restrict__ y,
+__global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, const T* __restrict__ x2, int C1, T* __restrict__ y,
                                                        const T* __restrict__ gamma, const T* __restrict__ beta,
                                                        int HW, int C, int cpg, int cb, float eps, int silu) {
   using V8 = typename Vec<T>::v8;
@@ -212,7 +227,9 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, 
   const bool act = rl < lanes;
   const int c0 = slice * cb + vi * 8;               // first channel of this thread's vector
   const int gpb = cb / cpg;                         // groups in the slice
-  const T* xb = x + ((long)img * HW) * C + c0;
+  const GnSrc<T> src = gn_src<T>(x, x2, C, C1, (long)img * HW, act ? c0 : 0);
+  const T* xb = src.base;
+  const long P = src.pitch;                          // row pitch of this thread's source
   T* yb = y + ((long)img * HW) * C + c0;
 
   float a[8], q[8];
@@ -221,8 +238,8 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, 
   if (act) {
     int r = rl;
     for (; r + 3 * lanes < HW; r += 4 * lanes) {
-      const V8 v0 = ld8<T>(xb + (long)r * C), v1 = ld8<T>(xb + (long)(r + lanes) * C);
-      const V8 v2 = ld8<T>(xb + (long)(r + 2 * lanes) * C), v3 = ld8<T>(xb + (long)(r + 3 * lanes) * C);
+      const V8 v0 = ld8<T>(xb + (long)r * P), v1 = ld8<T>(xb + (long)(r + lanes) * P);
+      const V8 v2 = ld8<T>(xb + (long)(r + 2 * lanes) * P), v3 = ld8<T>(xb + (long)(r + 3 * lanes) * P);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float f0 = to_f32(v0[e]), f1 = to_f32(v1[e]), f2 = to_f32(v2[e]), f3 = to_f32(v3[e]);
@@ -231,7 +248,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, 
       }
     }
     for (; r < HW; r += lanes) {
-      const V8 v0 = ld8<T>(xb + (long)r * C);
+      const V8 v0 = ld8<T>(xb + (long)r * P);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float f = to_f32(v0[e]); a[e] += f; q[e] += f * f; }
     }
@@ -305,14 +322,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x, 
   };
   int r = rl;
   for (; r + 3 * lanes < HW; r += 4 * lanes) {
-    const V8 v0 = ld8<T>(xb + (long)r * C), v1 = ld8<T>(xb + (long)(r + lanes) * C);
-    const V8 v2 = ld8<T>(xb + (long)(r + 2 * lanes) * C), v3 = ld8<T>(xb + (long)(r + 3 * lanes) * C);
+    const V8 v0 = ld8<T>(xb + (long)r * P), v1 = ld8<T>(xb + (long)(r + lanes) * P);
+    const V8 v2 = ld8<T>(xb + (long)(r + 2 * lanes) * P), v3 = ld8<T>(xb + (long)(r + 3 * lanes) * P);
     st8<T>(yb + (long)r * C, apply8(v0));
     st8<T>(yb + (long)(r + lanes) * C, apply8(v1));
     st8<T>(yb + (long)(r + 2 * lanes) * C, apply8(v2));
     st8<T>(yb + (long)(r + 3 * lanes) * C, apply8(v3));
   }
-  for (; r < HW; r += lanes) st8<T>(yb + (long)r * C, apply8(ld8<T>(xb + (long)r * C)));
+  for (; r < HW; r += lanes) st8<T>(yb + (long)r * C, apply8(ld8<T>(xb + (long)r * P)));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -670,7 +687,7 @@ extern "C" int hallo_groupnorm_chunks(int HW) {
 }
 
 template <typename T>
-static int launch_groupnorm(const void* x, void* y, const void* gamma, const void* beta, float* ws, int n_img,
+static int launch_groupnorm(const void* x, const void* x2, int C1, void* y, const void* gamma, const void* beta, float* ws, int n_img,
                             int HW, int C, int groups, float eps, int silu, hipStream_t st) {
   if (g_gn_fused && HW <= 1024) {
     // channel slice per workgroup: whole groups, a multiple of 8 channels, 40..128 channels
@@ -681,7 +698,7 @@ static int launch_groupnorm(const void* x, void* y, const void* gamma, const voi
     }
     if (cb > 0 && (long)(C / cb) * n_img >= 16) {
       hipLaunchKernelGGL((gn_fused_kernel<T>), dim3((unsigned)((C / cb) * n_img)), dim3(256), 0, st,
-                         reinterpret_cast<const T*>(x), reinterpret_cast<T*>(y), reinterpret_cast<const T*>(gamma),
+                         reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(x2), C1, reinterpret_cast<T*>(y), reinterpret_cast<const T*>(gamma),
                          reinterpret_cast<const T*>(beta), HW, C, cpg, cb, eps, silu);
       HALLO_CHECK_LAUNCH();
       return 0;
@@ -689,32 +706,42 @@ static int launch_groupnorm(const void* x, void* y, const void* gamma, const voi
   }
   const int nchunks = hallo_groupnorm_chunks(HW);
   const int rpc = (HW + nchunks - 1) / nchunks;
-  hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nchunks, n_img), dim3(256), 0, st, reinterpret_cast<const T*>(x), ws,
-                     HW, C, groups, rpc);
+  hipLaunchKernelGGL((gn_stats_kernel<T>), dim3(nchunks, n_img), dim3(256), 0, st, reinterpret_cast<const T*>(x),
+                     reinterpret_cast<const T*>(x2), C1, ws, HW, C, groups, rpc);
   // apply: ~16 KB of data per 256-thread block (measured: 32-64 KB blocks with 4 loads in flight are 25 % slower --
   // fewer, longer blocks lose more to the tail than the per-block statistics prologue costs)
   int rows_per_block = (8192 * 2) / (C * 2);
   if (rows_per_block < 1) rows_per_block = 1;
   const int nb = (HW + rows_per_block - 1) / rows_per_block;
   hipLaunchKernelGGL((gn_apply_kernel<T>), dim3(nb, n_img), dim3(256), 0, st, reinterpret_cast<const T*>(x),
-                     reinterpret_cast<T*>(y), reinterpret_cast<const T*>(gamma), reinterpret_cast<const T*>(beta), ws,
+                     reinterpret_cast<const T*>(x2), C1, reinterpret_cast<T*>(y), reinterpret_cast<const T*>(gamma), reinterpret_cast<const T*>(beta), ws,
                      HW, C, groups, nchunks, rows_per_block, eps, silu);
   HALLO_CHECK_LAUNCH();
   return 0;
 }
 
+extern "C" int hallo_groupnorm_nhwc2(const void* x, int C1, const void* x2, void* y, const void* gamma, const void* beta, float* workspace,
+                                     int n_img, int HW, int C, int groups, float eps, int silu, int dtype, void* stream);
+
 extern "C" int hallo_groupnorm_nhwc(const void* x, void* y, const void* gamma, const void* beta, float* workspace,
                                     int n_img, int HW, int C, int groups, float eps, int silu, int dtype,
                                     void* stream) {
+  return hallo_groupnorm_nhwc2(x, C, nullptr, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, dtype, stream);
+}
+
+extern "C" int hallo_groupnorm_nhwc2(const void* x, int C1, const void* x2, void* y, const void* gamma, const void* beta, float* workspace,
+                                     int n_img, int HW, int C, int groups, float eps, int silu, int dtype, void* stream) {
   if (!x || !y || !gamma || !beta || !workspace) return -22;
+  if (C1 <= 0 || C1 > C || (C1 & 7) || (C1 < C && !x2)) return -22;
+  if (C1 == C) x2 = nullptr;
   if (n_img <= 0 || HW <= 0 || C <= 0 || (C & 7) || groups <= 0 || groups > GN_MAX_GROUPS || C % groups) return -22;
   if (n_img > 65535) return -22;
   // the deterministic reduction gives a thread 6 (group, sum, sumsq) slots: one vector of 8 channels spanning <= 5
   // groups (channels per group >= 2), or two vectors (C > 2048) of <= 3 groups each
   if (C > 4096 || C / groups < 2) return -22;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == DT_F16) return launch_groupnorm<_Float16>(x, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, st);
-  if (dtype == DT_BF16) return launch_groupnorm<__bf16>(x, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, st);
+  if (dtype == DT_F16) return launch_groupnorm<_Float16>(x, x2, C1, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, st);
+  if (dtype == DT_BF16) return launch_groupnorm<__bf16>(x, x2, C1, y, gamma, beta, workspace, n_img, HW, C, groups, eps, silu, st);
   return -22;
 }
 

@@ -119,6 +119,8 @@ SYMBOLS = {
     "hallo_groupnorm_chunks": (C.c_int, [C.c_int]),
     "hallo_groupnorm_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "hallo_groupnorm_nhwc2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "hallo_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "hallo_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),

@@ -176,9 +176,10 @@ class GroupNorm(nn.Module):
         self.weight = _param(channels, one=True)
         self.bias = _param(channels)
 
-    def run(self, x, silu=False):
+    def run(self, x, silu=False, x2=None):
+        """x2: normalise the channel concatenation [x | x2] without materialising it (ops.groupnorm)."""
         n_img, HW, _ = x.shape
-        return ops.groupnorm(x, self.weight, self.bias, n_img, HW, self.groups, self.eps, silu=silu)
+        return ops.groupnorm(x, self.weight, self.bias, n_img, HW, self.groups, self.eps, silu=silu, x2=x2)
 
 
 class LayerNorm(nn.Module):

@@ -16,6 +16,9 @@ from .. import ops
 from .layers import Conv1x1, Conv3x3, GroupNorm, Linear
 
 
+SKIP_CONCAT_IN_PLACE = True      # False (bench.py --materialize-skip-concat): write the [x | skip] concatenation as rounds 1-5 did (A/B)
+
+
 class ResnetBlock3D(nn.Module):
     def __init__(self, in_channels, out_channels, temb_channels, eps=1e-5, groups=32, output_scale_factor=1.0):
         super().__init__()
@@ -28,14 +31,28 @@ class ResnetBlock3D(nn.Module):
         self.conv2 = Conv3x3(out_channels, out_channels)
         self.conv_shortcut = Conv1x1(in_channels, out_channels) if in_channels != out_channels else None
 
-    def run(self, x, H, W, temb=None, frames_per_temb=1):
+    def run(self, x, H, W, temb=None, frames_per_temb=1, x2=None):
         """x [n, H*W, Cin]; temb [n / frames_per_temb, Cout] = time_emb_proj(SiLU(emb)) (already projected:
-        the UNet computes all time projections of a step in one GEMM, see UNet3DConditionModel)."""
+        the UNet computes all time projections of a step in one GEMM, see UNet3DConditionModel).
+        x2 [n, H*W, C2] (round 6): the block's input is the channel concatenation [x | x2] -- the skip connection of an up block
+        (unet_3d_blocks.py:1131,1373) -- which is never written: norm1 reads both tensors in place (hallo_groupnorm_nhwc2) and the
+        1x1 shortcut is two GEMMs over the two K ranges of its weight, the second one adding into the first one's output."""
         n, HW, _ = x.shape
-        h = self.norm1.run(x, silu=True)
+        if x2 is not None and not SKIP_CONCAT_IN_PLACE:      # A/B: the materialised concatenation of rounds 1-5 (two copy2d launches)
+            Ca, Cb = x.shape[-1], x2.shape[-1]
+            cat = x.new_empty((n, HW, Ca + Cb))
+            ops.copy2d(x.view(n * HW, Ca), cat.view(n * HW, Ca + Cb), n * HW, Ca)
+            ops.copy2d(x2.view(n * HW, Cb), cat.view(n * HW, Ca + Cb)[:, Ca:], n * HW, Cb)
+            x, x2 = cat, None
+        h = self.norm1.run(x, silu=True, x2=x2)
         h = self.conv1.run(h, n, H, W, bias2=temb, bias2_rows_per_group=frames_per_temb * HW)
         h = self.norm2.run(h, silu=True)
-        if self.conv_shortcut is not None:
+        if x2 is not None:
+            assert self.conv_shortcut is not None, "a concatenated input always changes the width"
+            Ca, w = x.shape[-1], self.conv_shortcut.w2d
+            res = ops.gemm(x.view(n * HW, Ca), w[:, :Ca], self.conv_shortcut.bias)
+            res = ops.gemm(x2.view(n * HW, -1), w[:, Ca:], None, residual=res, out=res).view(n, HW, -1)
+        elif self.conv_shortcut is not None:
             res = self.conv_shortcut.run(x.view(n * HW, -1)).view(n, HW, -1)
         else:
             res = x

@@ -29,16 +29,6 @@ class _Config(dict):
             raise AttributeError(name) from None
 
 
-def _cat_channels(a, b):
-    n, L, Ca = a.shape
-    Cb = b.shape[2]
-    out = torch.empty((n, L, Ca + Cb), device=a.device, dtype=a.dtype)
-    o2 = out.view(n * L, Ca + Cb)
-    ops.copy2d(a.view(n * L, Ca), o2, n * L, Ca)
-    ops.copy2d(b.view(n * L, Cb), o2[:, Ca:], n * L, Cb)
-    return out
-
-
 class CrossAttnDownBlock2D(nn.Module):
     def __init__(self, in_channels, out_channels, temb_channels, num_layers, eps, groups, heads, cross_attention_dim,
                  add_downsample):
@@ -186,8 +176,7 @@ class UNet2DConditionModel(HalloModule):
         for bi, blk in enumerate(self.up_blocks):
             attns = getattr(blk, "attentions", None)
             for i, resnet in enumerate(blk.resnets):
-                x = _cat_channels(x, skips.pop())
-                x = resnet.run(x, H, W, temb=temb(resnet), frames_per_temb=1)
+                x = resnet.run(x, H, W, temb=temb(resnet), frames_per_temb=1, x2=skips.pop())     # [x | skip] read in place (round 6)
                 if attns is not None:
                     last = bi == n_up - 1 and i == len(blk.resnets) - 1
                     if last:

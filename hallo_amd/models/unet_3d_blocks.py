@@ -49,19 +49,8 @@ class StepState:
         return self.temb_all[:, o:o + resnet.out_channels]
 
 
-def _resnet(st, resnet, x, H, W):
-    return resnet.run(x, H, W, temb=st.temb(resnet), frames_per_temb=st.frames)
-
-
-def _cat_channels(a, b):
-    """[n, L, Ca] ++ [n, L, Cb] -> [n, L, Ca+Cb] (skip concatenation, unet_3d_blocks.py:1131,1373)."""
-    n, L, Ca = a.shape
-    Cb = b.shape[2]
-    out = torch.empty((n, L, Ca + Cb), device=a.device, dtype=a.dtype)
-    o2 = out.view(n * L, Ca + Cb)
-    ops.copy2d(a.view(n * L, Ca), o2, n * L, Ca)
-    ops.copy2d(b.view(n * L, Cb), o2[:, Ca:], n * L, Cb)
-    return out
+def _resnet(st, resnet, x, H, W, x2=None):
+    return resnet.run(x, H, W, temb=st.temb(resnet), frames_per_temb=st.frames, x2=x2)
 
 
 def _layer(st, x, H, W, attn, audio, motion, depth):
@@ -207,8 +196,7 @@ class CrossAttnUpBlock3D(nn.Module):
     def run(self, st, x, H, W, skips):
         for resnet, attn, audio, motion in zip(self.resnets, self.attentions, self.audio_modules, self.motion_modules):
             res, _, _ = skips.pop()
-            x = _cat_channels(x, res)
-            x = _resnet(st, resnet, x, H, W)
+            x = _resnet(st, resnet, x, H, W, x2=res)         # [x | skip] read in place: no concatenated tensor (round 6)
             x = _layer(st, x, H, W, attn, audio, motion, self.depth)
         if self.upsamplers is not None:
             x, H, W = self.upsamplers[0].run(x, H, W)
@@ -233,8 +221,7 @@ class UpBlock3D(nn.Module):
     def run(self, st, x, H, W, skips):
         for resnet in self.resnets:
             res, _, _ = skips.pop()
-            x = _cat_channels(x, res)
-            x = _resnet(st, resnet, x, H, W)
+            x = _resnet(st, resnet, x, H, W, x2=res)         # [x | skip] read in place: no concatenated tensor (round 6)
         if self.upsamplers is not None:
             x, H, W = self.upsamplers[0].run(x, H, W)
         return x, H, W

@@ -440,17 +440,20 @@ def temporal_attention(qkv, B, F, HW, Cdim, heads, *, out=None, scale=None, lead
     return out
 
 
-def groupnorm(x, gamma, beta, n_img, HW, groups, eps, *, silu=False, out=None):
-    """Per-frame GroupNorm (+SiLU) on x [n_img, HW, C]."""
+def groupnorm(x, gamma, beta, n_img, HW, groups, eps, *, silu=False, out=None, x2=None):
+    """Per-frame GroupNorm (+SiLU) on x [n_img, HW, C].  x2 [n_img, HW, C2]: the norm runs over the channel concatenation
+    [x | x2] read in place (hallo_groupnorm_nhwc2: the skip concatenation of the up blocks is never materialised); out is
+    [n_img, HW, C + C2]."""
     _chk_dev(x)
-    Cdim = x.shape[-1]
-    assert x.is_contiguous()
+    C1 = x.shape[-1]
+    Cdim = C1 + (x2.shape[-1] if x2 is not None else 0)
+    assert x.is_contiguous() and (x2 is None or (x2.is_contiguous() and x2.shape[:-1] == x.shape[:-1] and x2.dtype == x.dtype and C1 % 8 == 0))
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty(x.shape[:-1] + (Cdim,), device=x.device, dtype=x.dtype)
     lib = _l.load()
     ws = current_scratch(x.device).gn_ws(n_img * lib.hallo_groupnorm_chunks(HW) * groups * 2)
-    _l.check(lib.hallo_groupnorm_nhwc(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), n_img, HW, Cdim, groups, float(eps),
-                                      1 if silu else 0, dtype_code(x.dtype), _stream()), "hallo_groupnorm_nhwc")
+    _l.check(lib.hallo_groupnorm_nhwc2(_p(x), C1, _p(x2), _p(out), _p(gamma), _p(beta), _p(ws), n_img, HW, Cdim, groups, float(eps),
+                                       1 if silu else 0, dtype_code(x.dtype), _stream()), "hallo_groupnorm_nhwc2")
     return out
 
 

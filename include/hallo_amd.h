@@ -41,6 +41,8 @@ int hallo_abi_version(void);
  * "split_k" = 0 / 1 (auto, default); "gn_fused" = 0 / 1 (single-launch GroupNorm for small feature maps, default 1);
  * "v3_min_tiles" = smallest grid the auto rule gives to the big-tile kernel; round 4: "gemm4" = 0 off / 1 auto rule / 2 every
  * problem csrc/gemm4.hip covers, "gemm4_min_nk", "gemm_stage_min_tiles", "split_k_max" (cap of the split-K factor).
+ * Round 6: "splitk_nt" = 0 / 1 / 2 (non-temporal split-K slab stores (+ loads): A/B), "fp8_mx" = 1 (default) / 0 (hallo_gemm_fp8 on the MX-rate
+ * scaled MFMA with unit block scales, or on the non-scaled bf16-rate form); "gemm_variant" 7 / 8 (persistent big tile) no longer exist.
  * Returns -22 for unknown names / values. */
 int hallo_set_option(const char* name, int value);
 /* Read an option back; "last_gemm_kernel" = the kernel the last hallo_gemm / hallo_conv3x3_nhwc call launched, as
@@ -111,7 +113,8 @@ typedef struct hallo_gemm_desc {
    *   (the cost of hallo_row_stats), so the contract holds for any problem.  batch = 1, dtype output, no geglu.
    * ln_parts (in, with ln_colsum): when > 0, ln_stats is such a buffer -- [M][ln_parts][2] partial sums over the K columns of A
    *   (ln_parts = ceil(K / 64) for a hallo_gemm producer) -- and the kernel reduces them to mean / rstd (eps = ln_eps) for its
-   *   rows in its prologue, in slot order.  0: ln_stats is [M][2] (mean, rstd) as before (hallo_row_stats, hallo_face_xattn_stats). */
+   *   rows in its prologue, in slot order.  0: ln_stats is [M][2] (mean, rstd) as before (hallo_row_stats, hallo_face_xattn_stats).
+   *   Round 6: ln_parts > 0 must equal ceil(K / 64) and be <= 32 (a tile's rows x ln_parts pairs are staged in the operand LDS), else -22. */
   float* row_parts;
   int ln_parts;
   /* ABI v7: 1 = the caller guarantees that the last 64 KB of `workspace` were zero before the first launch that used this workspace
@@ -218,6 +221,13 @@ int hallo_temporal_attention_lead(const void* qkv, void* out, int B, int F, int 
 int hallo_groupnorm_chunks(int HW);
 int hallo_groupnorm_nhwc(const void* x, void* y, const void* gamma, const void* beta, float* workspace,
                          int n_img, int HW, int C, int groups, float eps, int silu, int dtype, void* stream);
+/* ABI v8 (round 6): the same GroupNorm over a channel CONCATENATION read in place: the C channels of a row are the C1 channels of
+ * x [n_img, HW, C1] followed by the C - C1 channels of x2 [n_img, HW, C - C1]; y is [n_img, HW, C].  Replaces
+ * `torch.cat([hidden_states, res_hidden_states], dim=1)` + norm1 of the up-block resnets (hallo/models/unet_3d_blocks.py:1131,1373;
+ * resnet.py:385): the concatenated tensor is never written.  Bit-identical to hallo_groupnorm_nhwc on the materialised concatenation
+ * (same per-column sums, same reduction order).  C1 % 8 == 0; C1 == C (x2 ignored) is hallo_groupnorm_nhwc. */
+int hallo_groupnorm_nhwc2(const void* x, int C1, const void* x2, void* y, const void* gamma, const void* beta, float* workspace,
+                          int n_img, int HW, int C, int groups, float eps, int silu, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * hallo_layernorm: row LayerNorm (eps 1e-5 default in torch) with optional positional
@@ -304,7 +314,9 @@ int hallo_gemm4_schedule(int M, int N, int K, int64_t workspace_bytes, int force
  * hallo_gemm_fp8: C[m, n] = alpha * lead(n) * (a_scale[m] * w_scale[n] * sum_k decode(A[m,k]) decode(B[n,k]) + bias[n]) +
  *   residual[m, n], fp32 accumulation on v_mfma_f32_32x32x16_fp8_fp8, output in `dtype` (fp16 / bf16);
  *   lead(n) = lead_alpha for n < lead_cols else 1 (the q columns of a fused q|k|v projection carry the softmax scale).
- *   K % 16 == 0, N % 8 == 0, lda / ldb multiples of 16 bytes, A / B / C 16-byte aligned. */
+ *   K % 16 == 0, N % 8 == 0, lda / ldb multiples of 16 bytes, A / B / C 16-byte aligned.
+ *   Round 6: the contraction is v_mfma_scale_f32_32x32x64_f8f6f4 with unit (E8M0 = 127) block scales -- the fp8-rate instruction; the per-row /
+ *   per-channel scales above are applied to the fp32 accumulators as before (hallo_set_option("fp8_mx", 0): the non-scaled 32x32x16 form). */
 int hallo_quant_rows_fp8(const void* x, int64_t ldx, void* q, float* scale, int64_t rows, int C, const void* gamma,
                          const void* beta, float eps, int dtype, void* stream);
 typedef struct {

@@ -244,7 +244,10 @@ def temporal_attention(qkv, B, Fr, HW, Cdim, heads, *, out=None, scale=None, lea
     return _store(res, out, qkv.dtype)
 
 
-def groupnorm(x, gamma, beta, n_img, HW, groups, eps, *, silu=False, out=None):
+def groupnorm(x, gamma, beta, n_img, HW, groups, eps, *, silu=False, out=None, x2=None):
+    if x2 is not None:
+        assert x2.is_contiguous() and x.shape[-1] % 8 == 0
+        x = torch.cat([x, x2], dim=-1)
     Cd = x.shape[-1]
     assert x.is_contiguous() and Cd <= 4096 and Cd // groups >= 2
     y = F.group_norm(x.float().view(n_img, HW, Cd).permute(0, 2, 1), groups, gamma.float(), beta.float(), eps)

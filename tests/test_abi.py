@@ -102,6 +102,8 @@ def test_every_entry_point_rejects_bad_arguments(lib):
     res['temporal_F33']=lib.hallo_temporal_attention(p,p,1,33,4,80,2,1.0,0,N)
     res['gn_null']=lib.hallo_groupnorm_nhwc(N,N,N,N,N,1,4,32,4,1e-5,0,0,N)
     res['gn_cpg1']=lib.hallo_groupnorm_nhwc(p,p,p,p,p,1,4,32,32,1e-5,0,0,N)
+    res['gn2_C1_not8']=lib.hallo_groupnorm_nhwc2(p,20,p,p,p,p,p,1,4,64,4,1e-5,0,0,N)
+    res['gn2_no_x2']=lib.hallo_groupnorm_nhwc2(p,32,N,p,p,p,p,1,4,64,4,1e-5,0,0,N)
     res['ln_null']=lib.hallo_layernorm(N,N,N,N,N,4,32,1e-5,1,1,0,N)
     res['ln_C_not8']=lib.hallo_layernorm(p,p,p,p,N,4,20,1e-5,1,1,0,N)
     res['softmax_null']=lib.hallo_softmax_rows(N,N,4,8,1.0,0,N)

@@ -684,6 +684,32 @@ def test_groupnorm(dtype, n, HW, Cd, silu, eps, report):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,HW,Ca,Cb", [(16, 4096, 320, 320), (4, 4096, 640, 320), (16, 1024, 640, 640), (8, 1024, 1280, 640), (16, 256, 1280, 1280),
+                                        (16, 64, 1280, 1280), (3, 100, 1280, 640), (2, 4000, 320, 640)])
+def test_groupnorm_two_sources(dtype, n, HW, Ca, Cb, report):
+    """hallo_groupnorm_nhwc2 (ABI v8): GroupNorm over the channel concatenation [x | x2] read in place -- the skip concatenation
+    in front of an up-block resnet's norm1 (hallo/models/unet_3d_blocks.py:1131,1373; resnet.py:385) -- at the six widths of the
+    up path (groups of 20 / 30 / 40 / 60 / 80 channels, most of them straddling the boundary between the two tensors), in both the
+    one-launch and the statistics + apply forms: bit-identical to hallo_groupnorm_nhwc on the materialised concatenation."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(n + HW + Ca + Cb)
+    xa = _rand((n, HW, Ca), dtype, g) + 0.5
+    xb = (_rand((n, HW, Cb), dtype, g).float() * 2.0 - 0.25).to(dtype)
+    gm, bt = _rand((Ca + Cb,), dtype, g), _rand((Ca + Cb,), dtype, g)
+    cat = torch.cat([xa, xb], dim=-1).contiguous()
+    for fused in (1, 0):
+        ops.set_option("gn_fused", fused)
+        try:
+            want = ops.groupnorm(cat, gm, bt, n, HW, 32, 1e-5, silu=True)
+            got = ops.groupnorm(xa, gm, bt, n, HW, 32, 1e-5, silu=True, x2=xb)
+        finally:
+            ops.set_option("gn_fused", 1)
+        assert got.shape == cat.shape and torch.equal(got, want), (fused, (got.float() - want.float()).abs().max().item())
+    _check(f"groupnorm_two_sources[{n},{HW},{Ca}+{Cb}]", got, ops_ref.groupnorm_nhwc(cat, gm, bt, 32, 1e-5, silu=True), dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,Cd", [(1000, 320), (333, 640), (64, 1280), (50, 768)])
 def test_layernorm(dtype, rows, Cd, report):
     from hallo_amd import ops
