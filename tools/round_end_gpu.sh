@@ -32,3 +32,6 @@ try:
 except Exception as e:
     print("no bench line:", e); print(open("gpurun_out/${TAG}_bench_plain.err").read()[-800:])
 PY
+# 5. a --steps that is not a multiple of the group size (groups of 4 + a remainder group, both captured in the warm-up)
+timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-configs2 --no-fp16-leg --no-serial-leg > gpurun_out/${TAG}_bench_steps5.log 2>&1
+grep -o '"value": [0-9.]*' gpurun_out/${TAG}_bench_steps5.log | head -1 | sed "s/^/steps5 /"; grep -o '"inflight_identity": {[^}]*}' gpurun_out/${TAG}_bench_steps5.log | head -1 | cut -c1-90
