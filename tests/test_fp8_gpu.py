@@ -83,7 +83,7 @@ def test_gemm_fp8(dtype, M, N, K, report):
     assert e3 < (3e-4 if dtype == torch.float16 else 2e-3) and same > 0.98, (e3, same)
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["fp16", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16], ids=["bf16"])      # configs[4] names bf16; the fp16 run cost 50 s of oracle time for the same path
 def test_pipeline_fp8_projections(dtype, report):
     """FaceAnimatePipeline (reduced width, CFG 3.5, 4 DDIM steps) with set_fp8_projections(True) on the denoising UNet vs the
     fp32 CPU oracle, and the size of the change against the 16-bit run of the same nets."""
