@@ -205,6 +205,9 @@ class FaceAnimatePipeline:
             raise ValueError("call_batch: K >= 1 clips, and no classifier-free guidance for K > 1 (the reference tiles the "
                              "banks of a CFG pair over the batch axis, mutual_self_attention.py:235-247: a batch of CFG pairs "
                              "has no single bank map)")
+        if K * video_length * (height // self.vae_scale_factor) * (width // self.vae_scale_factor) > (1 << 20):
+            raise ValueError("call_batch: K x frames x latent pixels is limited to 2^20 token rows per evaluation (16 clips of 16 frames at 512 x 512): "
+                             "the widest row-major intermediates (rows x 1280 ... 2560) are indexed with 32-bit element counts inside a tile walk")
         B = 2 if do_cfg else K                     # batch entries of one UNet evaluation
         mode = CLIP_BATCH if K > 1 else do_cfg     # the bank rule of the spatial self-attention (models/attention.py)
         Fr = video_length
