@@ -768,7 +768,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype + ("+fp8proj" if args.fp8_proj else ""), "data": "synthetic (random-init weights of the reference architecture, synthetic clip inputs)",
         "config": {"workload": f"{cfg_name} per GPU: 1 clip/step, {S}x{S}, {Fr} frames, {args.ddim_steps} DDIM "
-                               f"steps, guidance {args.guidance} ({'CFG, B=2' if args.guidance > 1 else 'no CFG, B=1'}), "
+                               f"steps, guidance {args.guidance} ({'CFG, B=2' if args.guidance > 1 else 'no CFG'}), {KB} independent clip(s) per UNet evaluation, "
                                "ReferenceNet + VAE encode/decode + D2H inside the timed region",
                    "launch": ("hipGraph replay of the UNet evaluation (steps 1.. of every clip)" if (not dry and pipe.use_graph) else (graph_note or "eager")),
                    "host_wall_in_enqueue_calls_ms_per_clip": round(host_s / args.steps * 1e3, 1),
