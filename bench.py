@@ -466,6 +466,7 @@ def main():
     ap.add_argument("--no-slot-wait", action="store_true", help="A/B: do not wait (blocking event) for a slot's previous clip before enqueuing its next one")
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: hallo_set_option(NAME, VALUE) before the pipeline is built (e.g. gemm4=0); recorded in config.options")
+    ap.add_argument("--audio-kpad8", action="store_true", help="A/B: the fused audio-branch GEMM over K = 3D + 8 (rounds 1-5) instead of 3D + 64 (a whole number of 64-deep K tiles)")
     ap.add_argument("--materialize-skip-concat", action="store_true",
                     help="A/B: write the [x | skip] channel concatenation in front of the up-block resnets (two copy2d launches each, rounds 1-5) "
                          "instead of reading both tensors in place (hallo_groupnorm_nhwc2 + split 1x1 shortcut, round 6)")
@@ -556,6 +557,9 @@ def main():
         for kv in args.set_option:
             k_, v_ = kv.split("=")
             routing[k_] = serial_routing[k_] = int(v_)
+        if args.audio_kpad8:
+            import hallo_amd.models.attention as _at
+            _at.AUDIO_K_PAD_TO_TILE = False
         if args.materialize_skip_concat:
             import hallo_amd.models.resnet as _rn
             _rn.SKIP_CONCAT_IN_PLACE = False

@@ -83,6 +83,7 @@ class _NoCache:
 
 NO_CACHE = _NoCache()
 SKIP_BANK = "skip_bank"      # `do_cfg` value of a B = 1 evaluation of the UNCOND half of a CFG pair: no row reads the reference bank
+AUDIO_K_PAD_TO_TILE = True   # False (bench.py --audio-kpad8, A/B): K = 3D + 8 for the fused audio-branch GEMM, as in rounds 1-5 (read at prepare())
 CLIP_BATCH = "clip_batch"    # `do_cfg` value of a batch of INDEPENDENT clips without CFG: frame row r reads the bank of clip r // frames
 
 
@@ -238,11 +239,14 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
         self.w_kv3 = torch.cat([a.to_k.weight for a in xs] + [a.to_v.weight for a in xs], 0).contiguous()  # [6D, Ca]
         # to_out followed by the zero conv is one linear map per branch (the mask between them is a per-row scalar):
         #   zero_conv_i(mask * (a_i Wo_i^T + bo_i)) = (mask * a_i) (Wz_i Wo_i)^T + mask * (Wz_i bo_i) + bz_i
-        # so the three branches + their sum are ONE GEMM over K = 3D (+8: three mask columns carrying Wz_i bo_i).
+        # so the three branches + their sum are ONE GEMM over K = 3D (+ three mask columns carrying Wz_i bo_i, padded to +64 so that K
+        # stays a multiple of the 64-deep K tile: 3D + 8 = 968 / 1928 / 3848 ran 14 / 21 / 56 % slower per launch than 3D + 64 = 1024 / 1984
+        # / 3904 -- a ragged last K tile, and no big-tile kernel -- tools/cbench, round 6).
         wz = [c.weight.view(D, D).float() for c in cv]
         wc = [wz[i] @ xs[i].to_out[0].weight.float() for i in range(3)]
         cc = [(wz[i] @ xs[i].to_out[0].bias.float())[:, None] for i in range(3)]
-        self.w_fused = torch.cat(wc + cc + [torch.zeros((D, 5), device=wc[0].device)], dim=1).to(dt).contiguous()   # [D, 3D+8]
+        self.kpad = 64 if ((3 * D) % 64 == 0 and AUDIO_K_PAD_TO_TILE) else 8
+        self.w_fused = torch.cat(wc + cc + [torch.zeros((D, self.kpad - 3), device=wc[0].device)], dim=1).to(dt).contiguous()   # [D, 3D+kpad]
         self.bz3 = torch.stack([c.bias.float() for c in cv])                                                   # [3, D] fp32
         # the three LayerNorms fold into the GEMMs that consume them (hallo_gemm ln_colsum)
         self.attn1._prepare()
@@ -275,8 +279,10 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
             return torch.stack([masks[i].reshape(-1).float() * ms[i] for i in range(3)]).contiguous()     # [3, n*L]
         msmask = cache.get(AudioTemporalBasicTransformerBlock, ("msmask", self.depth, n, L), scales)
 
+        KP = 3 * D + self.kpad
+
         def abuf():
-            buf = torch.zeros((n * L, 3 * D + 8), device=x.device, dtype=x.dtype)
+            buf = torch.zeros((n * L, KP), device=x.device, dtype=x.dtype)
             buf[:, 3 * D:3 * D + 3] = msmask.t().to(x.dtype)
             return buf
         A = cache.get(AudioTemporalBasicTransformerBlock, ("abuf", self.depth, n, L, D), abuf)
@@ -288,7 +294,7 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
         # three branches x heads as one attention launch; output rows pre-scaled by motion_scale[i] * mask_i
         # (attention.py:853-903) and written straight into the fused GEMM's A operand
         ops.attention(q3, kv3[:, :, :3 * D], kv3[:, :, 3 * D:], 3 * self.attn2_0.heads,
-                      out=A.view(n, L, 3 * D + 8)[:, :, :3 * D], rowscale=msmask, rowscale_head_div=self.attn2_0.heads,
+                      out=A.view(n, L, KP)[:, :, :3 * D], rowscale=msmask, rowscale_head_div=self.attn2_0.heads,
                       q_prescaled=True)
         if self.ff.takes_stats(n * L):
             x, st3 = ops.gemm(A, self.w_fused, bias_c, residual=x.view(n * L, D), row_parts=True)     # norm3's statistics
