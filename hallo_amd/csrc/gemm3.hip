@@ -366,10 +366,12 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmArgs p) {
             }
             V4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float hvv = __builtin_fmaf(vs, hv[j], __builtin_fmaf(vc, gh[j], bh[j]));
-              const float gu = __builtin_fmaf(gs, gv[j], __builtin_fmaf(gc, gg[j], bg[j]));
-              o[j] = from_f32<T>(hvv * gelu_u(gu));
+            for (int j = 0; j < 4; j += 2) {      // two columns per issue on the packed fp32 pipe (common.h gelu_u2)
+              const f32x2 hvv = pk_fma(f32x2{vs, vs}, f32x2{hv[j], hv[j + 1]}, pk_fma(f32x2{vc, vc}, f32x2{gh[j], gh[j + 1]}, f32x2{bh[j], bh[j + 1]}));
+              const f32x2 gu = pk_fma(f32x2{gs, gs}, f32x2{gv[j], gv[j + 1]}, pk_fma(f32x2{gc, gc}, f32x2{gg[j], gg[j + 1]}, f32x2{bg[j], bg[j + 1]}));
+              const f32x2 h = hvv * gelu_u2(gu);
+              o[j] = from_f32<T>(h[0]);
+              o[j + 1] = from_f32<T>(h[1]);
             }
             *reinterpret_cast<V4*>(C + (long)m * p.ldc + n) = o;
           }

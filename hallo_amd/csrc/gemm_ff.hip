@@ -54,6 +54,9 @@ constexpr int FF_LDS = FF_OFF_W2 + FF_W2_RING * 2 * FF_W2_SLOT;   // 155648
 static_assert(FF_LDS <= 160 * 1024, "LDS");
 constexpr int FF_DMA = FF_CHUNK / 1024 / 4;                   // 8 LDS-DMA instructions per wave per chunk: 5 of W1, 3 of W2 / b1
 constexpr int FF_DMA_W1 = FF_W1_BYTES / 1024 / 4;             // 5
+#ifndef FF_VALU_PER_MFMA
+#define FF_VALU_PER_MFMA 7
+#endif
 }  // namespace
 
 struct FfArgs {
@@ -175,13 +178,17 @@ __global__ __launch_bounds__(256) void ff320_kernel(const FfArgs p) {
   // GEGLU of one accumulator element pair: value register E, gate register E + 8 (common.h gelu_u: the scales ride in b1)
   f32x4 cb[2][4];                 // [chunk of the pair][value 0..3, value 8..11, gate 0..3, gate 8..11]
   float hf[16];
-  auto geglu_elem = [&](auto e_c, const f32x16& acc, const int c) {
+  // elements E, E + 1 (E even) of chunk c at once: the fma / mul pairs issue on the packed fp32 pipe (common.h gelu_u2)
+  auto geglu_pair = [&](auto e_c, const f32x16& acc, const int c) {
     constexpr int E = decltype(e_c)::value;
-    const float bv = cb[c][E >> 2][E & 3];
-    const float bg = cb[c][2 + (E >> 2)][E & 3];
-    const float hv = __builtin_fmaf(GELU_U_INV, acc[E], bv);
-    const float gu = __builtin_fmaf(GELU_U_SCALE, acc[E + 8], bg);
-    hf[c * 8 + E] = hv * gelu_u(gu);
+    static_assert((E & 1) == 0, "pair");
+    const f32x2 bv = {cb[c][E >> 2][E & 3], cb[c][E >> 2][(E & 3) + 1]};
+    const f32x2 bg = {cb[c][2 + (E >> 2)][E & 3], cb[c][2 + (E >> 2)][(E & 3) + 1]};
+    const f32x2 hv = pk_fma(f32x2{GELU_U_INV, GELU_U_INV}, f32x2{acc[E], acc[E + 1]}, bv);
+    const f32x2 gu = pk_fma(f32x2{GELU_U_SCALE, GELU_U_SCALE}, f32x2{acc[E + 8], acc[E + 9]}, bg);
+    const f32x2 h = hv * gelu_u2(gu);
+    hf[c * 8 + E] = h[0];
+    hf[c * 8 + E + 1] = h[1];
   };
   auto pack_h = [&](const int c) {
     V8 v;
@@ -241,13 +248,14 @@ __global__ __launch_bounds__(256) void ff320_kernel(const FfArgs p) {
           if constexpr (k + PFK < FF_K16) { FF_LOADW(k + PFK); }
         });
         if constexpr (PREV && OVL && R < 8 && !(VAR & 4)) {
-          geglu_elem(std::integral_constant<int, R>{}, p0, 0);
-          geglu_elem(std::integral_constant<int, R>{}, p1, 1);
-          asm volatile("" : "+v"(hf[R]), "+v"(hf[8 + R]));      // opaque uses INSIDE the region: without them the arithmetic sinks behind the last MFMA
+          // region R: one element PAIR -- (R, R + 1) of chunk 0 in the even regions, (R - 1, R) of chunk 1 in the odd ones
+          constexpr int E0 = R & ~1, CH = R & 1;
+          geglu_pair(std::integral_constant<int, E0>{}, CH ? p1 : p0, CH);
+          asm volatile("" : "+v"(hf[CH * 8 + E0]), "+v"(hf[CH * 8 + E0 + 1]));      // opaque uses INSIDE the region: without them the arithmetic sinks behind the last MFMA
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, FF_VALU_PER_MFMA, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(256) void ff320_kernel(const FfArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { hf[e] = p0[e] + p0[e + 8]; hf[8 + e] = p1[e] + p1[e + 8]; }
       } else if (!(OVL && CUR)) {
-        ff_static_for<0, 8>([&](auto ec) { geglu_elem(ec, p0, 0); geglu_elem(ec, p1, 1); });
+        ff_static_for<0, 4>([&](auto ec) { constexpr int E = 2 * decltype(ec)::value; geglu_pair(std::integral_constant<int, E>{}, p0, 0); geglu_pair(std::integral_constant<int, E>{}, p1, 1); });
       }
       const V8 pf0 = pack_h(0), pf1 = pack_h(1);
       // second GEMM of pair t-1: W2 fragments straight from the W2 ring (3 in flight), the 16 DMA issues of pair t+1 in between.
