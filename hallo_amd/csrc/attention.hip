@@ -1054,7 +1054,7 @@ extern "C" int hallo_set_option_fp8(const char* name, int value);
 extern "C" int hallo_set_option_attn(const char* name, int value) {
   if (name && !strcmp(name, "temporal_mfma")) { if (value < 0 || value > 2) return -22; g_temporal_mfma = value; return 0; }
   if (name && !strcmp(name, "attn_order")) { if (value < 0 || value > 2) return -22; g_attn_order = value; return 0; }
-  if (name && !strcmp(name, "attn40")) { if (value < 0 || value > 8) return -22; g_attn40 = value; set_attn40_variant(value); return 0; }
+  if (name && !strcmp(name, "attn40")) { if (value < 0 || value > 40) return -22; g_attn40 = value; set_attn40_variant(value); return 0; }
   if (name && !strcmp(name, "tok_attn")) { if (value < 0 || value > 2) return -22; g_tok_attn = value; return 0; }
   if (name && (!strcmp(name, "xattn_tiled") || !strcmp(name, "xattn_cap"))) return hallo_set_option_xattn(name, value);     // fused_xattn.hip
   return hallo_set_option_fp8(name, value);                                                                                  // fp8.hip

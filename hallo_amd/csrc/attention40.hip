@@ -53,8 +53,22 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 }  // namespace
 
-// EXA = exponentials (of 32 per tile) issued before the barrier; PRIO = raise the wave priority around the MFMA clusters
-template <typename T, int EXA, int PRIO>
+// EXA = exponentials (of 32 per tile) issued before the barrier; PRIO = raise the wave priority around the MFMA clusters.
+// ABL (-DHALLO_ABLATIONS builds, tools/cbench attn-time 10..15; WRONG results, timing only): 1 = no K fragment LDS reads (the Q
+// fragment stands in), 2 = no V fragment LDS reads (P stands in), 4 = the exponential is a multiplication (a full-rate VALU
+// instruction instead of a quarter-rate one), 8 = no exponentials and no converts at all, 16 = no running maximum, 32 = no K / V DMA (the LDS tiles keep their initial garbage), 64 = no
+// per-tile barrier, 128 = the per-tile barrier does not wait for the DMA queue (with 2: nothing in the loop does)
+//
+// PV48 (round 6): the second 32-row block of O^T -- d = 32..39, the row-sum row 40 and 23 rows of zeros -- as 16-row blocks on
+// v_mfma_f32_16x16x32: per 32 keys two MFMAs of 16 matrix cycles (one per 16 queries) instead of two of 32, i.e. 12.3 instead of
+// 14 32x32x16-equivalents per 64-key tile.  The timing ablations (profiles/r6_attn40_ablations.txt) say that is what counts: with
+// every LDS fragment read, exponential, convert and maximum REMOVED the kernel keeps 78 % of its time -- it is bound by the
+// matrix pipe at the clock the power limit allows, and 40 % of the MFMA work it executes is padding.  The 16x16x32 B operand wants
+// P^T as [8 keys of group lane>>4][query lane&15]: v_permlane16_swap of the dwords of pf[t][0] / pf[t][1] (the two 16-key slices
+// of a 32-key block, issued after the 32-row block's MFMAs have consumed them) leaves in the first register the operand of
+// queries 0..15 and in the second that of queries 16..31, key groups (slice, half) = (0,0) (1,0) (0,1) (1,1); the A operand is the
+// same transposing read of V plane B with the 16-lane group choosing (slice, half) instead of (d half, half).
+template <typename T, int EXA, int PRIO, int ABL = 0, bool PV48 = false>
 __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
@@ -166,8 +180,10 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
       o0 = (krow0 < cK_left) ? o0 : OOB;
       o1 = (krow1 < cK_left) ? o1 : OOB;
     }
+    if (!(ABL & 32)) {
     A40_DMA(cK_rs, k_dst0 + st, o0, cK_so);
     if (wave_u == 0) A40_DMA(cK_rs, k_dst1 + st, o1, cK_so);
+    }
     cK_so += cK_step; cK_left -= KVB;
     if (__builtin_expect(--cK_tiles == 0, 0)) {        // the next tile opens the second segment (if any)
       cK_rs = rsK2; cK_so = 0; cK_step = (int)(KVB * p.k2_rs * 2); cK_left = p.Lkv2; cK_tiles = nt2;
@@ -182,8 +198,10 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
       o0 = (vrow0 < cV_left) ? o0 : OOB;
       o1 = (vrow1 < cV_left) ? o1 : OOB;
     }
+    if (!(ABL & 32)) {
     A40_DMA(cV_rs, v_dst0 + st0, o0, cV_so);
     if (wave_u == 1) A40_DMA(cV_rs, v_dst1 + st1, o1, cV_so);
+    }
     cV_so += cV_step; cV_left -= KVB;
     if (__builtin_expect(--cV_tiles == 0, 0)) {
       cV_rs = rsV2; cV_so = 0; cV_step = (int)(KVB * p.v2_rs * 2); cV_left = p.Lkv2; cV_tiles = nt2;
@@ -204,11 +222,19 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
                                 : ((gi & 3) < 2 ? lds + A40_OFF_VB + (4 * hi + (gi >> 2)) * 16 + (gi & 3) * 8
                                                 : ((gi & 3) == 2 ? lds + A40_OFF_ONE + A40_PAD_ONE_SKEW : lds + A40_OFF_ZERO + A40_PAD_ZERO_SKEW));
 
+  // PV48: V fragment of the 16-row block d = 32..47 for v_mfma_f32_16x16x32: 16-lane group g = lane >> 4 = key group (slice g & 1,
+  // half g >> 1); lane i of the group addresses row 16 * slice + 4 * half + (i >> 2), 4 columns (i & 3) * 4
+  const int g16 = lane >> 4;
+  const lds_u8* const vbB16 = (gi & 3) < 2 ? lds + A40_OFF_VB + (16 * (g16 & 1) + 4 * (g16 >> 1) + (gi >> 2)) * 16 + (gi & 3) * 8
+                                           : ((gi & 3) == 2 ? lds + A40_OFF_ONE + A40_PAD_ONE_SKEW : lds + A40_OFF_ZERO + A40_PAD_ZERO_SKEW);
+
   f32x16 oacc[NDB];
 #pragma unroll
   for (int db = 0; db < NDB; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[db][r] = 0.0f;
+  // PV48: O^T rows 32..47 of queries 0..15 / 16..31: lane holds rows 32 + 4 * (lane >> 4) + r of query (lane & 15) (+ 16)
+  f32x4 o1a = {0.0f, 0.0f, 0.0f, 0.0f}, o1b = {0.0f, 0.0f, 0.0f, 0.0f};
   float m_run = 0.0f;
   constexpr float RESCALE_THR = 6.0f;   // log2 units: P <= 64
   const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -219,9 +245,9 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       typedef const __attribute__((address_space(3))) V8* ldsv8;
-      const V8 k0 = *(ldsv8)(kb01 + ST + t * 32 * 80);
-      const V8 k1 = *(ldsv8)(kb01 + ST + t * 32 * 80 + 32);
-      const V8 k2 = *(ldsv8)(kb2 + ST + t * 32 * 80);
+      const V8 k0 = (ABL & 1) ? qf[0] : *(ldsv8)(kb01 + ST + t * 32 * 80);
+      const V8 k1 = (ABL & 1) ? qf[1] : *(ldsv8)(kb01 + ST + t * 32 * 80 + 32);
+      const V8 k2 = (ABL & 1) ? qf[2] : *(ldsv8)(kb2 + ST + t * 32 * 80);
       sc[t] = Vec<T>::mfma32(k0, qf[0], zero16);
       sc[t] = Vec<T>::mfma32(k1, qf[1], sc[t]);
       sc[t] = Vec<T>::mfma32(k2, qf[2], sc[t]);
@@ -270,6 +296,8 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
     cons_left -= KVB;
     if (__builtin_expect(--cons_tiles == 0, 0)) { cons_left = p.Lkv2; cons_tiles = nt2; }
     float mx = -3.0e38f;
+    if (ABL & 16) mx = s_cur[0][0];
+    else
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -293,9 +321,14 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
       m_run = m_new;
       if (hi) qf[2][0] = from_f32<T>(-m_new);                  // Q'[row][40]
 #pragma unroll
-      for (int db = 0; db < NDB; ++db)
+      for (int db = 0; db < (PV48 ? 1 : NDB); ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      if (PV48) {      // the 16-row blocks hold query (lane & 15) (+ 16): its factor lives in that lane (this branch is wave-uniform)
+        const float aa = __shfl(alpha, lane & 15, 64), ab = __shfl(alpha, 16 + (lane & 15), 64);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o1a[r] *= aa; o1b[r] *= ab; }
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -307,14 +340,25 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
     if (MORE) qk(std::integral_constant<int, 1 - PAR>{}, s_nxt);
     if (PRIO) __builtin_amdgcn_s_setprio(0);
     V8 pf[NT][2];
+    auto pexp = [&](float x) { return (ABL & 4) ? x * 0.001f : __builtin_amdgcn_exp2f(x); };
+    if (ABL & 8) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 lo = {s_cur[t][0], s_cur[t][1], s_cur[t][2], s_cur[t][3]}, hi4 = {s_cur[t][4], s_cur[t][5], s_cur[t][6], s_cur[t][7]};
+        pf[t][0] = __builtin_bit_cast(V8, lo);
+        pf[t][1] = __builtin_bit_cast(V8, hi4);
+      }
+    } else
 #pragma unroll
     for (int e = 0; e < EXA; ++e)
-      pf[e >> 4][(e >> 3) & 1][e & 7] = from_f32<T>(__builtin_amdgcn_exp2f(s_cur[e >> 4][e & 15]));
-    __syncthreads();        // B
+      pf[e >> 4][(e >> 3) & 1][e & 7] = from_f32<T>(pexp(s_cur[e >> 4][e & 15]));
+    if (ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    else if (!(ABL & 64)) __syncthreads();        // B
     // ---- C: remaining exponentials | O^T += V^T . P^T of tile it ----
+    if (!(ABL & 8))
 #pragma unroll
     for (int e = EXA; e < 32; ++e)
-      pf[e >> 4][(e >> 3) & 1][e & 7] = from_f32<T>(__builtin_amdgcn_exp2f(s_cur[e >> 4][e & 15]));
+      pf[e >> 4][(e >> 3) & 1][e & 7] = from_f32<T>(pexp(s_cur[e >> 4][e & 15]));
     if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -322,17 +366,38 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
       for (int h2 = 0; h2 < 2; ++h2) {
         const int row0 = t * 32 + h2 * 16;       // slots 0..3: kv = row0 + 4*hi + j; slots 4..7: kv = row0 + 8 + 4*hi + j
         {
+          if (ABL & 2) oacc[0] = Vec<T>::mfma32(pf[t][h2 ^ 1], pf[t][h2], oacc[0]);
+          else {
           const s16x4 lo = tr4(vbA + PAR * A40_VA_TILE + row0 * 64);
           const s16x4 hi4 = tr4(vbA + PAR * A40_VA_TILE + (row0 + 8) * 64);
           const s16x8 v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
           oacc[0] = Vec<T>::mfma32(__builtin_bit_cast(V8, v), pf[t][h2], oacc[0]);
+          }
         }
-        {
+        if (!PV48) {
+          if (ABL & 2) oacc[1] = Vec<T>::mfma32(pf[t ^ 1][h2], pf[t][h2], oacc[1]);
+          else {
           const s16x4 lo = tr4(vbB + PAR * A40_VB_TILE + row0 * 16);
           const s16x4 hi4 = tr4(vbB + PAR * A40_VB_TILE + (row0 + 8) * 16);
           const s16x8 v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
           oacc[1] = Vec<T>::mfma32(__builtin_bit_cast(V8, v), pf[t][h2], oacc[1]);
+          }
         }
+      }
+      if (PV48) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const u32x4 p0 = __builtin_bit_cast(u32x4, pf[t][0]), p1 = __builtin_bit_cast(u32x4, pf[t][1]);
+        u32x4 bq0, bq1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(p0[d], p1[d], false, false);
+          bq0[d] = sw[0]; bq1[d] = sw[1];
+        }
+        const s16x4 lo = tr4(vbB16 + PAR * A40_VB_TILE + t * 32 * 16);
+        const s16x4 hi4 = tr4(vbB16 + PAR * A40_VB_TILE + (t * 32 + 8) * 16);
+        const V8 v = __builtin_bit_cast(V8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+        o1a = Vec<T>::mfma16(v, __builtin_bit_cast(V8, bq0), o1a);
+        o1b = Vec<T>::mfma16(v, __builtin_bit_cast(V8, bq1), o1b);
       }
     }
     if (PRIO) __builtin_amdgcn_s_setprio(0);
@@ -359,7 +424,13 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   }
 
   // ---- normalise and store: lane owns row q0+l31, d = db*32 + (r&3) + 8*(r>>2) + 4*hi ----
-  const float l_tot = __shfl(oacc[L_DB][L_R], l31, 64);       // row 40 of O^T lives in the hi = 0 lane of column q
+  float l_tot;
+  if (PV48) {      // row 40 = row 8 of the 16-row block: register 0 of lane 32 + (query & 15), first / second query half
+    const float lt_a = __shfl(o1a[0], 32 + (l31 & 15), 64), lt_b = __shfl(o1b[0], 32 + (l31 & 15), 64);
+    l_tot = (l31 & 16) ? lt_b : lt_a;
+  } else {
+    l_tot = __shfl(oacc[L_DB][L_R], l31, 64);       // row 40 of O^T lives in the hi = 0 lane of column q
+  }
   float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
   if (p.o_rowscale && q0 + l31 < p.Lq) inv *= p.o_rowscale[(long)(h / p.rs_hdiv) * p.rs_stride + (long)b * p.Lq + q0 + l31];
   {
@@ -369,7 +440,7 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
     const bool live = q0 + l31 < p.Lq;
     unsigned pk[5][2];
 #pragma unroll
-    for (int g = 0; g < 5; ++g) {
+    for (int g = 0; g < (PV48 ? 4 : 5); ++g) {
       V4 w;
 #pragma unroll
       for (int j = 0; j < 4; ++j) w[j] = from_f32<T>(oacc[g >> 2][(g & 3) * 4 + j] * inv);     // d = 8g + 4hi + j
@@ -382,7 +453,22 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
       const auto y = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
       if (live) *reinterpret_cast<uint4*>(orow + 8 * g + 8 * hi) = make_uint4(x[0], y[0], x[1], y[1]);
     }
-    {                                    // d 32 .. 39: lanes hi = 0 collect the partner's half and store alone
+    if (PV48) {
+      // d 32 .. 39 of query qa = lane & 15 (o1a) and qa + 16 (o1b): lanes 0..15 hold d 32..35, lanes 16..31 d 36..39; lanes 0..15
+      // fetch the partner's half and store 16 contiguous bytes per query
+      const int qa = lane & 15;
+      const float inv_a = __shfl(inv, qa, 64), inv_b = __shfl(inv, 16 + qa, 64);
+      V4 wa, wb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { wa[j] = from_f32<T>(o1a[j] * inv_a); wb[j] = from_f32<T>(o1b[j] * inv_b); }
+      const uint2 ua = __builtin_bit_cast(uint2, wa), ub = __builtin_bit_cast(uint2, wb);
+      const unsigned ax = __shfl(ua.x, 16 + qa, 64), ay = __shfl(ua.y, 16 + qa, 64);
+      const unsigned bx = __shfl(ub.x, 16 + qa, 64), by = __shfl(ub.y, 16 + qa, 64);
+      if (lane < 16) {
+        if (q0 + qa < p.Lq) *reinterpret_cast<uint4*>(Og + (long)(q0 + qa) * p.o_rs + 32) = make_uint4(ua.x, ua.y, ax, ay);
+        if (q0 + 16 + qa < p.Lq) *reinterpret_cast<uint4*>(Og + (long)(q0 + 16 + qa) * p.o_rs + 32) = make_uint4(ub.x, ub.y, bx, by);
+      }
+    } else {                             // d 32 .. 39: lanes hi = 0 collect the partner's half and store alone
       unsigned c0 = pk[4][0], c1 = pk[4][1];           // opaque copies: see the note at the row-maximum exchange
       asm volatile("" : "+v"(c0), "+v"(c1));
       const auto x = __builtin_amdgcn_permlane32_swap(pk[4][0], c0, false, false);
@@ -392,17 +478,43 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   }
 }
 
-static int g_attn40_variant = 1;     // hallo_set_option("attn40", v): 0 = attention.hip, 1.. = schedule variants of this kernel (A/B)
+// hallo_set_option("attn40", v): 0 = attention.hip; 1 (default) = this kernel, the 48-row PV form (PV48, all exponentials before the
+// barrier) at the 64 x 64-latent level (>= 2048 queries: -0.7...1.2 % per launch, bit-identical outputs in tools/cbench attn-det) and the
+// 64-row form below it (256 x 256-pixel clips, 1024 queries: the 48-row form is 2-5 % slower there); 2.. = fixed forms for A/B:
+// 2 / 3 / 5 = 64-row PV with 0 / 32 / 8 exponentials before the barrier, 4 = raised wave priority around the MFMA clusters,
+// 6 / 7 / 8 = PV48 with 16 / 0 / 32, 9 = the 64-row form of rounds 2-5 (16) at every size
+static int g_attn40_variant = 1;
 
 void set_attn40_variant(int v) { g_attn40_variant = v; }
 
 template <typename T>
 static void launch_variant(const AttnArgs& a, dim3 grid, hipStream_t st) {
   switch (g_attn40_variant) {
+    case 1:
+      if (a.nqb >= 16) hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((attn40_kernel<T, 16, 0>), grid, dim3(256), 0, st, a);
+      break;
     case 2: hipLaunchKernelGGL((attn40_kernel<T, 0, 0>), grid, dim3(256), 0, st, a); break;
     case 3: hipLaunchKernelGGL((attn40_kernel<T, 32, 0>), grid, dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL((attn40_kernel<T, 16, 1>), grid, dim3(256), 0, st, a); break;
     case 5: hipLaunchKernelGGL((attn40_kernel<T, 8, 0>), grid, dim3(256), 0, st, a); break;
+    case 6: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 0, true>), grid, dim3(256), 0, st, a); break;
+    case 7: hipLaunchKernelGGL((attn40_kernel<T, 0, 0, 0, true>), grid, dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true>), grid, dim3(256), 0, st, a); break;
+#ifdef HALLO_ABLATIONS
+    case 10: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 1>), grid, dim3(256), 0, st, a); break;
+    case 11: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 2>), grid, dim3(256), 0, st, a); break;
+    case 12: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 3>), grid, dim3(256), 0, st, a); break;
+    case 13: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 4>), grid, dim3(256), 0, st, a); break;
+    case 14: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 8>), grid, dim3(256), 0, st, a); break;
+    case 15: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 16>), grid, dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 8 + 16>), grid, dim3(256), 0, st, a); break;
+    case 17: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 3 + 8 + 16>), grid, dim3(256), 0, st, a); break;
+    case 18: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 32>), grid, dim3(256), 0, st, a); break;
+    case 19: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 32 + 3 + 8 + 16>), grid, dim3(256), 0, st, a); break;
+    case 20: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 32 + 64>), grid, dim3(256), 0, st, a); break;
+    case 21: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 2 + 128>), grid, dim3(256), 0, st, a); break;
+#endif
     default: hipLaunchKernelGGL((attn40_kernel<T, 16, 0>), grid, dim3(256), 0, st, a); break;
   }
 }

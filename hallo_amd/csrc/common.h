@@ -28,12 +28,19 @@ template <> struct Vec<_Float16> {
   static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
+  // 16x16x32: A lane l holds A[i = l&15][k = (l>>4)*8 .. +7], B lane l holds B[k = (l>>4)*8 .. +7][j = l&15], D lane l holds D[i = (l>>4)*4 + r][j = l&15]
+  static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
 };
 template <> struct Vec<__bf16> {
   using v8 = bf16x8;
   using v4 = bf16x4;
   static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   }
 };
 

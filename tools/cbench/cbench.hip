@@ -182,7 +182,8 @@ static int cmd_attn_det(int argc, char** argv) {
   const int H = 8, HD = 40, C = H * HD;
   const AttnCase cases[] = {{"4x1024 self (the pytest case, unscaled q)", 4, 1024, 0}, {"4x1024 self+bank", 4, 1024, 1},
                             {"2x4096 self+bank", 2, 4096, 1}, {"3x1000 ragged self+bank", 3, 1000, 1}};
-  std::vector<int> variants = {0, 1, 2, 3, 4, 5};
+  std::vector<int> variants = {0, 1, 2, 3, 4, 5, 6};
+  if (argc > 0) { variants.clear(); for (char* t = strtok(argv[0], ","); t; t = strtok(nullptr, ",")) variants.push_back(atoi(t)); }
   int bad = 0;
   for (int dt = 0; dt < 2; ++dt)
     for (const AttnCase& c : cases) {
