@@ -126,8 +126,8 @@ class OpProfiler:
 
         def c_gemm(a, k, r):
             M, K = a[0].shape
-            N = r.shape[1]
             mult = 2 if k.get("geglu") else 1
+            N = a[1].shape[0] // mult          # (not the output's width: with kv_split the K / V columns leave in a second tensor)
             return 2.0 * M * N * K * mult, es * (M * K + N * K * mult + M * N * (2 if k.get("residual") is not None else 1))
 
         def c_gemmb(a, k, r):
@@ -143,9 +143,9 @@ class OpProfiler:
         def c_attn(a, k, r):
             q, k1 = a[0], a[1]
             B, Lq, Cq = q.shape
-            L1 = k1.shape[1]
+            L1 = k1.shape[2] if k1.dim() == 4 else k1.shape[1]          # 4-D: head-major [B, heads, L, head_dim]
             k2 = k.get("k2")
-            L2 = k2.shape[1] if k2 is not None else 0
+            L2 = (k2.shape[2] if k2.dim() == 4 else k2.shape[1]) if k2 is not None else 0
             nb2 = B - k.get("kv2_first_batch", 0) if k2 is not None else 0
             fl = 4.0 * Cq * Lq * (B * L1 + nb2 * L2)
             by = es * Cq * (2 * B * Lq + 2 * B * L1 + 2 * (k2.shape[0] * L2 if k2 is not None else 0))
@@ -204,7 +204,7 @@ class OpProfiler:
             ms_ = s.elapsed_time(e)
             tables = [(self.by_shape, (name, shp)), (fam, name), (self.by_symbol, sym)]
             if name == "attention":        # shp = (q shape, k1 shape, v1 shape[, ("k2", shape)]): classify by the K/V length
-                lkv = shp[1][1]
+                lkv = shp[1][2] if len(shp[1]) == 4 else shp[1][1]
                 af = "spatial self-attention (K/V >= 256 tokens, compute-bound)" if lkv >= 256 else \
                      "token cross-attention (K/V = 4 face / 3 x 32 audio tokens, HBM-bound)"
                 tables.append((self.attn_families, af))
@@ -469,6 +469,8 @@ def main():
     ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
                     help="A/B: hallo_set_option(NAME, VALUE) before the pipeline is built (e.g. gemm4=0); recorded in config.options")
     ap.add_argument("--audio-kpad8", action="store_true", help="A/B: the fused audio-branch GEMM over K = 3D + 8 (rounds 1-5) instead of 3D + 64 (a whole number of 64-deep K tiles)")
+    ap.add_argument("--no-kv-head-major", action="store_true",
+                    help="A/B: the 64 x 64-level self-attentions read K / V as column views of the fused q|k|v buffer (rounds 1-5) instead of head-major tensors")
     ap.add_argument("--materialize-skip-concat", action="store_true",
                     help="A/B: write the [x | skip] channel concatenation in front of the up-block resnets (two copy2d launches each, rounds 1-5) "
                          "instead of reading both tensors in place (hallo_groupnorm_nhwc2 + split 1x1 shortcut, round 6)")
@@ -562,6 +564,8 @@ def main():
         if args.audio_kpad8:
             import hallo_amd.models.attention as _at
             _at.AUDIO_K_PAD_TO_TILE = False
+        if args.no_kv_head_major:
+            _ops.KV_HEAD_MAJOR = False
         if args.materialize_skip_concat:
             import hallo_amd.models.resnet as _rn
             _rn.SKIP_CONCAT_IN_PLACE = False

@@ -21,6 +21,7 @@
 // from LDS with the same permutation (two 8-byte reads per fragment).
 #include "common.h"
 #include "attn_args.h"
+#include <stdlib.h>
 #include "../../include/hallo_amd.h"
 #include <type_traits>
 #include <string.h>
@@ -1010,6 +1011,16 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
   a.rs_hdiv = d->o_rowscale_head_div > 0 ? d->o_rowscale_head_div : d->heads;
   a.rs_stride = d->o_rowscale_stride;
   a.head_fastest = (g_attn_order == 1 || (g_attn_order == 2 && a.Lkv1 + a.Lkv2 <= 128)) ? 1 : 0;
+  a.hs1 = d->kv1_hs > 0 ? d->kv1_hs : d->head_dim;
+  a.hs2 = d->kv2_hs > 0 ? d->kv2_hs : d->head_dim;
+  const bool head_strides = a.hs1 != d->head_dim || a.hs2 != d->head_dim;
+  if (head_strides && ((a.hs1 | a.hs2) & 7)) return -22;
+#ifdef HALLO_ABLATIONS
+  if (getenv("HALLO_ATTN_KV_HEAD_MAJOR") && d->head_dim == 40) {      // timing only: read the same buffers AS IF K / V were stored [batch][head][row][40]
+    a.k1_rs = a.v1_rs = 40; a.hs1 = (long)a.Lkv1 * 40; a.k1_bs = a.v1_bs = (long)a.heads * a.Lkv1 * 40;
+    a.k2_rs = a.v2_rs = 40; a.hs2 = (long)a.Lkv2 * 40; a.k2_bs = a.v2_bs = (long)a.heads * a.Lkv2 * 40;
+  }
+#endif
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // attention40.hip stages K / V with 16-byte LDS-DMA (buffer addressing drops misaligned low address bits) and stores 16
   // bytes per lane: every K / V base, row and batch stride and the output must be 16-byte aligned, else the generic kernel
@@ -1019,7 +1030,7 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
   // token cross-attention: K/V of <= 32 rows, one segment, pre-scaled q, whole head groups, everything 16-byte aligned
   {
     const int hgp = d->head_dim == 40 ? 8 : (d->head_dim == 80 ? 4 : 2);
-    if (g_tok_attn && !d->k2 && d->Lkv1 <= 32 && d->q_prescaled != 0 && (d->dtype == DT_F16 || d->dtype == DT_BF16) && kv_aligned &&
+    if (g_tok_attn && !head_strides && !d->k2 && d->Lkv1 <= 32 && d->q_prescaled != 0 && (d->dtype == DT_F16 || d->dtype == DT_BF16) && kv_aligned &&
         d->heads % hgp == 0 && al16(d->q) && al16(d->o) && !((d->q_bs | d->o_bs | d->o_rs) & 7)) {
       g_last_attn = 3;
       if (d->dtype == DT_F16) return launch_tok_attn<_Float16>(a, d->head_dim, st);
@@ -1031,6 +1042,7 @@ extern "C" int hallo_attention(const hallo_attn_desc* d, void* stream) {
     g_last_attn = 2;
     return launch_attn40(a, d->dtype, st);          // attention40.hip: LDS-DMA staging + transposing V reads
   }
+  if (head_strides) return -22;       // only attention40.hip takes head strides
   g_last_attn = 1;
   if (d->dtype == DT_F16) return launch_attn<_Float16>(a, d->head_dim, d->q_prescaled != 0, st);
   if (d->dtype == DT_BF16) return launch_attn<__bf16>(a, d->head_dim, d->q_prescaled != 0, st);

@@ -95,12 +95,12 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   const int b = bid;
 
   const T* __restrict__ Qg = reinterpret_cast<const T*>(p.q) + (long)b * p.q_bs + h * HD;
-  const T* __restrict__ K1 = reinterpret_cast<const T*>(p.k1) + (long)b * p.k1_bs + h * HD;
-  const T* __restrict__ V1 = reinterpret_cast<const T*>(p.v1) + (long)b * p.v1_bs + h * HD;
+  const T* __restrict__ K1 = reinterpret_cast<const T*>(p.k1) + (long)b * p.k1_bs + h * p.hs1;
+  const T* __restrict__ V1 = reinterpret_cast<const T*>(p.v1) + (long)b * p.v1_bs + h * p.hs1;
   const bool use2 = p.k2 != nullptr && p.Lkv2 > 0 && b >= p.kv2_first;
   const int b2 = use2 ? (p.kv2_mod > 0 ? (b / p.kv2_div) % p.kv2_mod : b / p.kv2_div) : 0;
-  const T* __restrict__ K2 = use2 ? reinterpret_cast<const T*>(p.k2) + (long)b2 * p.k2_bs + h * HD : K1;
-  const T* __restrict__ V2 = use2 ? reinterpret_cast<const T*>(p.v2) + (long)b2 * p.v2_bs + h * HD : V1;
+  const T* __restrict__ K2 = use2 ? reinterpret_cast<const T*>(p.k2) + (long)b2 * p.k2_bs + h * p.hs2 : K1;
+  const T* __restrict__ V2 = use2 ? reinterpret_cast<const T*>(p.v2) + (long)b2 * p.v2_bs + h * p.hs2 : V1;
   T* __restrict__ Og = reinterpret_cast<T*>(p.o) + (long)b * p.o_bs + h * HD;
 
   // ---- LDS constants ----

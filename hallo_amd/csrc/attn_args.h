@@ -19,6 +19,9 @@ struct AttnArgs {
   // run); 1 = HEAD fastest (short K/V, e.g. the 32 audio / 4 face tokens: nothing to keep, but the heads of one query block
   // share the 128-byte lines of Q and O -- 80-byte head slices at head dim 40 -- so they should run together)
   int head_fastest;
+  // head strides of K / V in elements (attention40.hip): head_dim = the heads of a row are adjacent (every caller today);
+  // Lkv * head_dim with row stride head_dim = head-major K / V (a tile is one contiguous 5 KB: timing experiment, HALLO_ABLATIONS)
+  long hs1, hs2;
 };
 
 // attention40.hip: head dim 40, pre-scaled q.  Returns 0 or a negative status like the other launchers.

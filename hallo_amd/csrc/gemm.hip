@@ -899,6 +899,7 @@ static int launch_gemm_impl(GemmArgs a, bool conv, bool geglu, int batch, void* 
     g_last_kernel = 500 + (geglu ? 20 : 0) + 1 + (lnf ? 1000 : 0);
     return launch_gemm_rs2<T>(a, geglu, st);
   }
+  if (a.kv_out) return -22;       // only gemm_rs2.hip writes head-major K / V (hallo_gemm_kv_split_ok)
   if (g_gemm_rs && v >= 3 && a.vec_ok && gemm_rs_eligible(a, conv, geglu, batch)) {
     // 4xx: gemm_rs_kernel (A rows in registers, W streamed): + 10 * mode (0 gemm, 2 geglu) + (1: K = 320, 2: K = 640), + 1000 with LayerNorm
     g_last_kernel = 400 + (geglu ? 20 : 0) + (a.K == 320 ? 1 : 2) + (lnf ? 1000 : 0);
@@ -1136,6 +1137,14 @@ extern "C" int hallo_gemm(const hallo_gemm_desc* d, void* stream) {
   if (d->ln_parts > 0 && (d->ln_parts != (d->K + 63) / 64 || d->ln_parts > 32)) return -22;
   a.ws_zeroed = d->workspace_zeroed != 0;
   a.row_parts = d->row_parts;
+  a.kv_out = d->kv_out; a.kv_col0 = d->kv_col0; a.kv_L = d->kv_rows_per_image; a.kv_tstride = d->kv_tensor_stride;
+  if (a.kv_out) {
+    // K and V of 8 heads x 40 behind the q columns, whole images of kv_rows_per_image rows, LayerNorm-fused dtype output, nothing
+    // else in the epilogue; 16-byte stores
+    if (d->geglu || d->batch != 1 || d->out_f32 || d->residual || d->rowscale || d->row_parts || !d->ln_colsum || d->ln_stats) return -22;
+    if (d->kv_col0 < 0 || (d->kv_col0 & 31) || d->N - d->kv_col0 != 640 || d->ldc < d->kv_col0 || d->lead_cols > d->kv_col0) return -22;
+    if (d->kv_rows_per_image <= 0 || d->M % d->kv_rows_per_image || (d->kv_tensor_stride & 7) || (reinterpret_cast<uintptr_t>(d->kv_out) & 15)) return -22;
+  }
   if (a.row_parts && (d->batch != 1 || d->out_f32 || d->geglu || (d->N & 7) || (reinterpret_cast<uintptr_t>(d->row_parts) & 15))) return -22;
   a.tiles_m = (d->M + BM - 1) / BM;
   a.tiles_n = d->geglu ? (d->N + 63) / 64 : (d->N + BN - 1) / BN;
@@ -1177,6 +1186,17 @@ extern "C" int hallo_gemm_fuses_row_stats(int M, int N, int K, int geglu, int bi
   return gemm_rs_eligible(a, false, geglu != 0, 1) ? 1 : 0;
 }
 
+extern "C" int hallo_gemm_kv_split_ok(int M, int N, int K, int kv_col0) {
+  if (g_gemm_rs < 2 || g_gemm_variant < 3 || N - kv_col0 != 640 || (kv_col0 & 31) || kv_col0 < 0) return 0;
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = kv_col0 > 0 ? kv_col0 : 8;
+  a.bias2_rpg = 1; a.lead_cols = kv_col0; a.splits = 1; a.act = ACT_NONE;
+  a.ln_colsum = reinterpret_cast<const float*>(16);
+  a.A = a.C = reinterpret_cast<void*>(16);
+  return gemm_rs2_eligible(a, false, false, 1) ? 1 : 0;
+}
+
 extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
   if (!d || !d->x || !d->w || !d->y) return -22;
   if (d->n_img <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || (d->Cin & 7) || d->Cout <= 0) return -22;
@@ -1194,6 +1214,7 @@ extern "C" int hallo_conv3x3_nhwc(const hallo_conv_desc* d, void* stream) {
   a.residual = d->residual; a.ldr = d->ldr > 0 ? d->ldr : d->Cout; a.sR = 0;
   a.alpha = d->alpha; a.act = d->act; a.out_f32 = 0;
   a.lead_cols = 0; a.lead_alpha = 1.0f;
+  a.kv_out = nullptr; a.kv_col0 = 0; a.kv_L = 0; a.kv_tstride = 0;
   a.ln_colsum = nullptr; a.ln_eps = 0.0f; a.ln_stats = nullptr; a.ln_parts = 0; a.row_parts = nullptr; a.ws_zeroed = 0;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;

@@ -37,6 +37,10 @@ struct GemmArgs {
   // conv gather
   int H, W, Cin, OH, OW, stride, pad_t, pad_l, upsample;
   int conv_fast;   // Cin % 64 == 0 and no upsample: one tap per K tile, scalar tap offsets
+  // hallo_gemm_desc.kv_out (gemm_rs2.hip only): columns >= kv_col0 leave as head-major [image][8 heads][kv_L rows][40] K / V tensors
+  void* kv_out;
+  int kv_col0, kv_L;
+  long kv_tstride;
 };
 
 // gemm3.hip: 256x320 / 128x320 tile kernel (8 waves, LDS-DMA, one barrier per K step).  MODE 0 gemm, 1 conv3x3

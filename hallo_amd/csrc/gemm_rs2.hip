@@ -58,7 +58,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // ABL (timing ablations, wrong results; hallo_set_option("gemm_rs_dbg", bits)): 1 = no stores, 2 = no epilogue, 5 = no stores and
 // no MFMAs (the epilogue's VALU work alone)
-template <typename T, bool GEGLU, bool LNF, int ABL>
+// KVS (hallo_gemm_desc.kv_out, round 6): the columns from p.kv_col0 on -- K then V of 8 heads x 40 -- are stored head-major,
+// [image][head][row][40], where hallo_attention's LDS-DMA reads a 64-key tile as one contiguous 5 KB piece.  A lane's 16-byte store
+// covers 8 columns of one head (40 = 5 x 8), so only the store ADDRESS changes: per store two constant divisions on the column.
+template <typename T, bool GEGLU, bool LNF, int ABL, bool KVS = false>
 __global__ __launch_bounds__(512, 2) void gemm_rs2_kernel(const GemmArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
@@ -185,6 +188,20 @@ __global__ __launch_bounds__(512, 2) void gemm_rs2_kernel(const GemmArgs p) {
   const int m = m0 + l31;
   T* const crow = C + (long)min(m, p.M - 1) * p.ldc;
   const bool row_live = m < p.M;
+  // KVS: this lane's row inside the head-major tensors: image m / L, row m % L; head h and tensor t add h * L * 40 + t * stride
+  T* kvrow = nullptr;
+  if (KVS) {
+    const int mm = min(m, p.M - 1), img = mm / p.kv_L, pos = mm - img * p.kv_L;
+    kvrow = reinterpret_cast<T*>(p.kv_out) + ((long)img * 8 * p.kv_L + pos) * 40;
+  }
+  auto out_ptr = [&](const int nc) -> T* {
+    if (KVS && nc >= p.kv_col0) {
+      const unsigned c = (unsigned)(nc - p.kv_col0);          // < 640
+      const unsigned t = c >= 320u ? 1u : 0u, cc = c - t * 320u, h = cc / 40u, d = cc - h * 40u;
+      return kvrow + (long)t * p.kv_tstride + (long)h * p.kv_L * 40 + d;
+    }
+    return crow + nc;
+  };
   const f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   const float lead = p.lead_alpha, alpha = p.alpha;
 
@@ -222,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rs2_kernel(const GemmArgs p) {
         const auto y = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
         const int nc = n0 + ob * 32 + 8 * (g - 1) + 8 * hi;
         if (ABL & 1) { R2_KEEP(x); R2_KEEP(y); }
-        else if (row_live && nc < p.N) *reinterpret_cast<uint4*>(crow + nc) = make_uint4(x[0], y[0], x[1], y[1]);
+        else if (row_live && nc < p.N) *reinterpret_cast<uint4*>(out_ptr(nc)) = make_uint4(x[0], y[0], x[1], y[1]);
       }
     }
   };
@@ -340,17 +357,17 @@ static void rs2_grid(int M, int npairs, int* full, int* slices, int* grid) {
 static int g_rs2_dbg = 0;
 void set_gemm_rs2_dbg(int v) { g_rs2_dbg = v; }
 
-template <typename T, bool G, bool L, int ABL>
+template <typename T, bool G, bool L, int ABL, bool KVS = false>
 static int launch_rs2_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
   static bool attr_done[64] = {};    // per device: the opt-in to > 64 KB of dynamic LDS belongs to the device's function
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -19;
   if (!attr_done[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rs2_kernel<T, G, L, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, R2_LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rs2_kernel<T, G, L, ABL, KVS>), hipFuncAttributeMaxDynamicSharedMemorySize, R2_LDS) != hipSuccess)
       return -12;
     attr_done[dev] = true;
   }
-  hipLaunchKernelGGL((gemm_rs2_kernel<T, G, L, ABL>), grid, dim3(512), R2_LDS, st, a);
+  hipLaunchKernelGGL((gemm_rs2_kernel<T, G, L, ABL, KVS>), grid, dim3(512), R2_LDS, st, a);
   return 0;
 }
 
@@ -374,7 +391,8 @@ int launch_gemm_rs2(const GemmArgs& a0, bool geglu, hipStream_t st) {
     else { if (abl == 1) rc = launch_rs2_one<T, false, true, 1>(a, grid, st); else rc = launch_rs2_one<T, false, true, 2>(a, grid, st); }
   } else
 #endif
-  if (geglu) { if (lnf) rc = launch_rs2_one<T, true, true, 0>(a, grid, st); else rc = launch_rs2_one<T, true, false, 0>(a, grid, st); }
+  if (a.kv_out) { if (geglu || !lnf) return -22; rc = launch_rs2_one<T, false, true, 0, true>(a, grid, st); }
+  else if (geglu) { if (lnf) rc = launch_rs2_one<T, true, true, 0>(a, grid, st); else rc = launch_rs2_one<T, true, false, 0>(a, grid, st); }
   else { if (lnf) rc = launch_rs2_one<T, false, true, 0>(a, grid, st); else rc = launch_rs2_one<T, false, false, 0>(a, grid, st); }
   if (rc) return rc;
   HALLO_CHECK_LAUNCH();

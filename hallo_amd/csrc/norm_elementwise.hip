@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const T* __restrict__ mo,
 
 using namespace hallo;
 
-extern "C" int hallo_abi_version(void) { return 8; }   // v8 (round 6): hallo_temporal_attention_lead; v7 (round 5): hallo_gemm_desc.row_parts / ln_parts, hallo_face_xattn_stats
+extern "C" int hallo_abi_version(void) { return 9; }   // v9 (round 6): hallo_gemm_desc.kv_out (head-major K / V), hallo_attn_desc.kv1_hs / kv2_hs; v8 (round 6): hallo_temporal_attention_lead; v7 (round 5): hallo_gemm_desc.row_parts / ln_parts, hallo_face_xattn_stats
 
 static int g_gn_fused = 1;   // hallo_set_option("gn_fused", 0 | 1): single-launch GroupNorm for small feature maps
 

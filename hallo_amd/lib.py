@@ -47,6 +47,7 @@ class GemmDesc(C.Structure):
         ("row_parts", C.c_void_p),
         ("ln_parts", C.c_int),
         ("workspace_zeroed", C.c_int),
+        ("kv_out", C.c_void_p), ("kv_col0", C.c_int), ("kv_rows_per_image", C.c_int), ("kv_tensor_stride", C.c_int64),
     ]
 
 
@@ -96,6 +97,7 @@ class AttnDesc(C.Structure):
         ("dtype", C.c_int),
         ("o_rowscale", C.c_void_p), ("o_rowscale_head_div", C.c_int), ("o_rowscale_stride", C.c_int64),
         ("q_prescaled", C.c_int),
+        ("kv1_hs", C.c_int64), ("kv2_hs", C.c_int64),
     ]
 
 
@@ -132,6 +134,7 @@ SYMBOLS = {
                                          C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "hallo_row_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "hallo_gemm_fuses_row_stats": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "hallo_gemm_kv_split_ok": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "hallo_gemm4_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
     "hallo_face_xattn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),

@@ -151,28 +151,33 @@ class TemporalBasicTransformerBlock(nn.Module):
         b = n // video_length
         bb, _, row0 = bank_layout if bank_layout is not None else (b, 0, 0)
         a1 = self.attn1
-        _, q, k, v = a1.qkv_ln(x, stats=stats)       # stats: norm1's statistics from proj_in's epilogue
+        _, q, k, v = a1.qkv_ln(x, stats=stats, kv_head_major=True)       # stats: norm1's statistics from proj_in's epilogue
+        # head-major K / V (4-D: the 320-channel level on the row-stationary GEMM): the bank's K / V follow, re-laid once per clip
+        hm = k.dim() == 4
+        bank_tag = "bank_kv_hm" if hm else "bank_kv"
+        lay = (lambda kv2: ops.head_major(kv2[0], kv2[1], a1.heads)) if hm else (lambda kv2: kv2)
+        hmk = dict(kv1_head_major=True, kv2_head_major=True) if hm else {}
         if do_cfg == CLIP_BATCH:
             assert bank_layout is None
-            k2, v2 = cache.get(self, "bank_kv", lambda: a1.kv(bank.view(b, -1, L, Cd)[:, 0].to(x.dtype).contiguous()))
+            k2, v2 = cache.get(self, bank_tag, lambda: lay(a1.kv(bank.view(b, -1, L, Cd)[:, 0].to(x.dtype).contiguous())))
             a = ops.attention(q, k, v, a1.heads, k2=k2, v2=v2, kv2_batch_div=video_length, kv2_batch_mod=0, kv2_first_batch=0,
-                              q_prescaled=True)
+                              q_prescaled=True, **hmk)
         elif do_cfg == SKIP_BANK:
             # the uncond half of a CFG evaluation run on its own (FaceAnimatePipeline(cfg_split=True)): its rows attend to
             # themselves only (mutual_self_attention.py:264-284), the bank segment does not exist for this call
-            a = ops.attention(q, k, v, a1.heads, q_prescaled=True)
+            a = ops.attention(q, k, v, a1.heads, q_prescaled=True, **({"kv1_head_major": True} if hm else {}))
         else:
             def bank_kv():
                 ref = bank.view(bb, -1, L, Cd)[:, 0].to(x.dtype)     # d_b[:, 0]: the reference image's features
                 if row0 % bb:
                     ref = ref.roll(-(row0 % bb), 0)                  # local row j is global row row0 + j
-                return a1.kv(ref.contiguous())
-            k2, v2 = cache.get(self, "bank_kv", bank_kv)
+                return lay(a1.kv(ref.contiguous()))
+            k2, v2 = cache.get(self, bank_tag, bank_kv)
             # K/V = [self ; bank]: frame row r reads bank entry r % b (the reference's `.repeat(1, f, 1, 1)` on the
             # 3-D tensor tiles the batch axis, mutual_self_attention.py:235-247); with CFG the first half of the
             # rows (uncond) skips the bank segment (:264-284).
             a = ops.attention(q, k, v, a1.heads, k2=k2, v2=v2, kv2_batch_div=1, kv2_batch_mod=bb,
-                              kv2_first_batch=(n // 2 if do_cfg else 0), q_prescaled=True)
+                              kv2_first_batch=(n // 2 if do_cfg else 0), q_prescaled=True, **hmk)
         x = a1.out(a, residual=x)
 
         a2 = self.attn2
@@ -258,8 +263,8 @@ class AudioTemporalBasicTransformerBlock(nn.Module):
         """x [n, L, D]; audio [n, 32, Ca]; masks = (full, face, lip), each fp32 [n, L] for this block's depth.
         stats: norm1's statistics of x from proj_in's epilogue, if any."""
         n, L, D = x.shape
-        _, q, k, v = self.attn1.qkv_ln(x, stats=stats)
-        a = ops.attention(q, k, v, self.attn1.heads, q_prescaled=True)
+        _, q, k, v = self.attn1.qkv_ln(x, stats=stats, kv_head_major=True)
+        a = ops.attention(q, k, v, self.attn1.heads, q_prescaled=True, **({"kv1_head_major": True} if k.dim() == 4 else {}))
         st2 = None
         if ops.wants_stats(n * L, 3 * D, D):
             x, st2 = self.attn1.out(a, residual=x, row_parts=True)     # norm2's statistics from to_out's epilogue

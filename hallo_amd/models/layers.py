@@ -259,11 +259,19 @@ class Attention(nn.Module):
             self._o8, self._o8s = ops.quant_rows_fp8(self.to_out[0].weight)
         self.fp8 = bool(enabled) and not self.is_cross
 
-    def qkv_ln(self, x, bias2=None, bias2_rows_per_group=0, stats=None):
+    def qkv_ln(self, x, bias2=None, bias2_rows_per_group=0, stats=None, kv_head_major=False):
         """x [N, L, C] UN-normalised -> fused [N, L, 3*inner] of LN(x) (+ bias2: PE @ W^T rows), q pre-scaled.
-        stats: LayerNorm statistics of x's rows from the kernel that produced x (ops.RowParts / [rows, 2]), if any."""
+        stats: LayerNorm statistics of x's rows from the kernel that produced x (ops.RowParts / [rows, 2]), if any.
+        kv_head_major: the caller can take K / V as contiguous [N, heads, L, head_dim] tensors (hallo_attention with head strides).
+        Where the GEMM that runs this projection can write them that way (ops.kv_split_ok: the 320-channel level) the result is
+        (None, q [N, L, inner], k4, v4) -- 4-D k / v say so; everywhere else the usual column views of one buffer."""
         N, L, Cd = x.shape
         x2 = x.view(N * L, Cd)
+        if (kv_head_major and ops.KV_HEAD_MAJOR and not self.fp8 and bias2 is None and self.heads == 8 and self.dim_head == 40
+                and x2.is_contiguous() and ops.kv_split_ok(N * L, 3 * self.inner, Cd, self.inner)):     # (that kernel takes the statistics from its A rows)
+            q, kv = ops.gemm(x2, self._ln_w, self._ln_b, lead_cols=self.inner, lead_alpha=ops.q_scale(self.dim_head),
+                             ln_colsum=self._ln_g, ln_eps=self._ln_eps, kv_split=(self.inner, L))
+            return None, q.view(N, L, self.inner), kv[0], kv[1]
         if self.fp8 and bias2 is None:
             # LayerNorm + row quantisation in one pass over x, then the fp8 GEMM; the q columns carry the softmax scale
             xq, sa = ops.quant_rows_fp8(x2, self._ln_norm.weight, self._ln_norm.bias, self._ln_eps)

@@ -241,8 +241,12 @@ class RowParts:
 
 def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, act=ACT_NONE, geglu=False,
          bias2=None, bias2_rows_per_group=0, out_f32=False, bias_per_row=False, lead_cols=0, lead_alpha=1.0,
-         ln_colsum=None, ln_eps=1e-5, ln_stats=None, row_parts=False):
+         ln_colsum=None, ln_eps=1e-5, ln_stats=None, row_parts=False, kv_split=None):
     """out[M,N] = act(alpha * rowscale * (a[M,K] @ w[N,K]^T + bias) + residual).
+
+    kv_split = (col0, L) (only where kv_split_ok() says so): returns (out [M, col0], kv [2, M // L, 8, L, 40]) -- the columns from
+    col0 on, K then V of 8 heads x 40, leave the GEMM head-major (hallo_gemm_desc.kv_out), the layout attention(kv1_head_major=True)
+    reads.
 
     a may be a 2-D view with arbitrary row stride (last dim contiguous).  geglu: w is [2N,K].
     row_parts=True: returns (out, RowParts) -- the output rows' LayerNorm partial sums from the epilogue.
@@ -252,11 +256,19 @@ def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, 
     M, K = a.shape
     N = w.shape[0] // 2 if geglu else w.shape[0]
     assert w.shape[1] == K, (a.shape, w.shape)
-    if out is None:
+    kv = None
+    if kv_split is not None:
+        col0, L = kv_split
+        assert out is None and not geglu and not out_f32 and N - col0 == 640 and M % L == 0 and lead_cols <= col0
+        out = torch.empty((M, col0), device=a.device, dtype=a.dtype)
+        kv = torch.empty((2, M // L, 8, L, 40), device=a.device, dtype=a.dtype)
+    elif out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
-    assert out.stride(1) == 1 and out.shape[0] == M and out.shape[1] == N
+    assert out.stride(1) == 1 and out.shape[0] == M and (out.shape[1] == N or kv is not None)
     d = _l.GemmDesc()
     d.A, d.B, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    if kv is not None:
+        d.kv_out, d.kv_col0, d.kv_rows_per_image, d.kv_tensor_stride = kv.data_ptr(), col0, L, kv.stride(0)
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc = a.stride(0), w.stride(0), out.stride(0)
     d.batch = 1
@@ -302,7 +314,18 @@ def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, 
     ws = _workspace(a.device)
     d.workspace, d.workspace_bytes, d.workspace_zeroed = ws.data_ptr(), SPLITK_WS_BYTES, WS_ZEROED
     _l.check(_l.load().hallo_gemm(C.byref(d), _stream()), "hallo_gemm")
+    if kv is not None:
+        return out, kv
     return (out, parts) if row_parts else out
+
+
+KV_HEAD_MAJOR = True      # False (bench.py --no-kv-head-major, A/B): the spatial self-attentions keep K / V as column views of the fused q|k|v buffer
+
+
+def kv_split_ok(M, N, K, col0):
+    """True when gemm(..., ln_colsum=..., kv_split=(col0, L)) is available for this problem under the current routing options (the
+    row-stationary K = 320 kernel takes it: hallo_gemm_kv_split_ok)."""
+    return bool(_l.load().hallo_gemm_kv_split_ok(M, N, K, col0))
 
 
 def gemm_batched(a, w, out, *, out_f32=False, alpha=1.0, bias=None, bias_per_row=False, bias_stride=None, act=ACT_NONE,
@@ -373,14 +396,18 @@ def conv3x3(x, w, bias, n_img, H, W, *, stride=1, pad_t=1, pad_l=1, out_hw=None,
 
 
 def attention(q, k1, v1, heads, *, k2=None, v2=None, kv2_batch_div=1, kv2_batch_mod=0, kv2_first_batch=0, out=None,
-              scale=None, rowscale=None, rowscale_head_div=0, q_prescaled=False):
+              scale=None, rowscale=None, rowscale_head_div=0, q_prescaled=False, kv1_head_major=False, kv2_head_major=False):
     """softmax(q k^T * scale) v over up to two key/value segments.
 
     q [B, Lq, C], k1/v1 [B, Lkv1, C], k2/v2 [B2, Lkv2, C] are views with contiguous last dim
-    (e.g. column slices of a fused projection buffer); C = heads * head_dim."""
+    (e.g. column slices of a fused projection buffer); C = heads * head_dim.
+    kvN_head_major: that segment's K / V are contiguous [B, heads, Lkv, head_dim] tensors (gemm(kv_split=...), head_major())."""
     _chk_dev(q, k1, v1)
     B, Lq, Cq = q.shape
     hd = Cq // heads
+    if kv1_head_major or kv2_head_major:
+        return _attention_head_major(q, k1, v1, heads, k2, v2, kv2_batch_div, kv2_batch_mod, kv2_first_batch, out, rowscale,
+                                     rowscale_head_div, q_prescaled, kv1_head_major, kv2_head_major)
     if out is None:
         out = torch.empty((B, Lq, Cq), device=q.device, dtype=q.dtype)
     d = _l.AttnDesc()
@@ -415,6 +442,51 @@ def attention(q, k1, v1, heads, *, k2=None, v2=None, kv2_batch_div=1, kv2_batch_
         d.o_rowscale, d.o_rowscale_head_div, d.o_rowscale_stride = None, 0, 0
     _l.check(_l.load().hallo_attention(C.byref(d), _stream()), "hallo_attention")
     return out
+
+
+def _attention_head_major(q, k1, v1, heads, k2, v2, kv2_batch_div, kv2_batch_mod, kv2_first_batch, out, rowscale, rowscale_head_div,
+                          q_prescaled, hm1, hm2):
+    """attention() with head-major K / V in segment 1 and / or 2 (hallo_attn_desc.kv1_hs / kv2_hs: head dim 40, pre-scaled q)."""
+    assert q_prescaled and rowscale is None
+    B, Lq, Cq = q.shape
+    hd = Cq // heads
+    if out is None:
+        out = torch.empty((B, Lq, Cq), device=q.device, dtype=q.dtype)
+    d = _l.AttnDesc()
+    d.q, d.k1, d.v1, d.o = q.data_ptr(), k1.data_ptr(), v1.data_ptr(), out.data_ptr()
+    d.batch, d.heads, d.head_dim, d.Lq = B, heads, hd, Lq
+    assert q.stride(2) == 1 and out.stride(2) == 1
+    d.q_bs, d.q_rs, d.o_bs, d.o_rs = q.stride(0), q.stride(1), out.stride(0), out.stride(1)
+
+    def seg(k, v, hm):
+        if hm:
+            assert k.dim() == 4 and k.shape[1] == heads and k.shape[3] == hd and k.is_contiguous() and v.is_contiguous() and v.shape == k.shape
+            L = k.shape[2]
+            bs = heads * L * hd if k.shape[0] > 1 else 0
+            return L, bs, hd, bs, hd, L * hd
+        assert k.stride(2) == 1 and v.stride(2) == 1
+        return k.shape[1], (k.stride(0) if k.shape[0] > 1 else 0), k.stride(1), (v.stride(0) if v.shape[0] > 1 else 0), v.stride(1), 0
+    d.Lkv1, d.k1_bs, d.k1_rs, d.v1_bs, d.v1_rs, d.kv1_hs = seg(k1, v1, hm1)
+    if k2 is not None:
+        d.k2, d.v2 = k2.data_ptr(), v2.data_ptr()
+        d.Lkv2, d.k2_bs, d.k2_rs, d.v2_bs, d.v2_rs, d.kv2_hs = seg(k2, v2, hm2)
+    else:
+        d.k2 = d.v2 = None
+        d.Lkv2 = 0
+    d.kv2_batch_div, d.kv2_batch_mod, d.kv2_first_batch = kv2_batch_div, kv2_batch_mod, kv2_first_batch
+    d.scale = float(hd ** -0.5)
+    d.dtype = dtype_code(q.dtype)
+    d.q_prescaled = 1
+    d.o_rowscale, d.o_rowscale_head_div, d.o_rowscale_stride = None, 0, 0
+    _l.check(_l.load().hallo_attention(C.byref(d), _stream()), "hallo_attention(head-major)")
+    return out
+
+
+def head_major(k, v, heads):
+    """[B, L, C] K / V views -> contiguous [B, heads, L, C // heads] copies (per-clip constants: the reference bank's K / V)."""
+    B, L, Cd = k.shape
+    f = lambda t: t.reshape(B, L, heads, Cd // heads).permute(0, 2, 1, 3).contiguous()
+    return f(k), f(v)
 
 
 LOG2E = 1.4426950408889634

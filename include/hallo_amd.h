@@ -121,8 +121,23 @@ typedef struct hallo_gemm_desc {
    * and have been written by nothing but hallo_gemm since (the stream-K kernel's arrival counters; every launch restores them).
    * 0 (what a v6-style caller that hands over uninitialised scratch gets): K-split tails are not used -- whole tiles only. */
   int workspace_zeroed;
+  /* ABI v9 (round 6): HEAD-MAJOR K / V straight from the fused to_q|to_k|to_v projection of the 320-channel level (8 heads x 40:
+   * hallo/models/mutual_self_attention.py:253-284, attention.py:828-831).  With kv_out != NULL the output columns n >= kv_col0 are
+   * not written to C but to kv_out: column kv_col0 + t * 320 + h * 40 + d of row m (t = 0: K, 1: V) goes to
+   *   kv_out + t * kv_tensor_stride + (((m / kv_rows_per_image) * 8 + h) * kv_rows_per_image + m % kv_rows_per_image) * 40 + d
+   * i.e. [image][head][row][40] tensors, the layout hallo_attention reads with kv1_hs = kv_rows_per_image * 40 and a row stride of
+   * 40: a 64-key tile of a head is then ONE contiguous 5 KB piece instead of 64 80-byte pieces at a 1920-byte pitch (8-12 % of the
+   * attention kernel's time, profiles/r6_attn40_headmajor.txt).  C keeps the columns below kv_col0 (ldc >= kv_col0).  Only the
+   * row-stationary K = 320 kernel has this epilogue: ask hallo_gemm_kv_split_ok() first; any other routing returns -22. */
+  void* kv_out;
+  int kv_col0;
+  int kv_rows_per_image;
+  int64_t kv_tensor_stride;
 } hallo_gemm_desc;
 int hallo_gemm(const hallo_gemm_desc* d, void* stream);
+/* 1 when hallo_gemm would run an [M, N] x K problem with fused LayerNorm and lead_cols = kv_col0 on the kernel that implements
+ * kv_out (N - kv_col0 must be 640: K and V of 8 heads x 40), under the current routing options. */
+int hallo_gemm_kv_split_ok(int M, int N, int K, int kv_col0);
 
 /* ------------------------------------------------------------------------------------------
  * hallo_conv3x3_nhwc: implicit-GEMM 3x3 convolution on token-major activations.
@@ -187,6 +202,10 @@ typedef struct hallo_attn_desc {
   int o_rowscale_head_div;      /* <= 0: all heads share one scale vector */
   int64_t o_rowscale_stride;
   int q_prescaled;              /* 1: q already carries scale * log2(e) (hallo_gemm lead_alpha); `scale` is ignored */
+  /* ABI v9: head strides of segment 1 / 2 in elements; 0 = head_dim (the heads of a row are adjacent, every layout above).
+   * kvN_hs = LkvN * head_dim with kN_rs = vN_rs = head_dim is the head-major layout hallo_gemm's kv_out writes.  head_dim 40 with
+   * q_prescaled only (the LDS-DMA kernel); anything else with a non-zero stride returns -22. */
+  int64_t kv1_hs, kv2_hs;
 } hallo_attn_desc;
 int hallo_attention(const hallo_attn_desc* d, void* stream);
 

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported(lib):
     assert declared == set(hl.SYMBOLS), (declared ^ set(hl.SYMBOLS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hallo_abi_version() == 8
+    assert lib.hallo_abi_version() == 9
 
 
 def test_struct_sizes_match_header(lib):

@@ -548,3 +548,66 @@ def test_gemm4_auto_rule(report):
     assert took[(4096, 1280, 5120)] == 6, took
     assert all(v != 6 for k, v in took.items() if k != (4096, 1280, 5120)), took
     report.append({"test": "gemm4_auto_rule", "kernel_family_by_shape": {str(k): v for k, v in took.items()}})
+
+
+# --------------------------------------------------------------------------------------------
+# round 6: head-major K / V (hallo_gemm_desc.kv_out, hallo_attn_desc.kv1_hs / kv2_hs)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,L", [(16384, 4096), (9216, 1024), (8192 + 4096, 4096)])
+def test_gemm_kv_split_is_the_plain_projection_relaid(dtype, M, L, report):
+    """The fused LayerNorm q|k|v projection with K / V written head-major equals the plain launch's columns bit for bit (same
+    kernel, same arithmetic: only the store address changes)."""
+    from hallo_amd import ops
+    g = torch.Generator().manual_seed(M + L)
+    Cd, H, hd = 320, 8, 40
+    x = _rand((M, Cd), dtype, g)
+    w = _rand((3 * Cd, Cd), dtype, g, scale=Cd ** -0.5)
+    b = _rand((3 * Cd,), dtype, g, scale=0.1)
+    gamma = (1.0 + 0.1 * torch.randn(Cd, generator=g)).to(dtype).to(x.device)
+    beta = (0.1 * torch.randn(Cd, generator=g)).to(dtype).to(x.device)
+    wf, gs, bf = ops.fold_layernorm(gamma, beta, w, b)
+    if not ops.kv_split_ok(M, 3 * Cd, Cd, Cd):
+        pytest.skip("the row-stationary kernel does not take this problem")
+    kw = dict(lead_cols=Cd, lead_alpha=ops.q_scale(hd), ln_colsum=gs, ln_eps=1e-5)
+    y = ops.gemm(x, wf, bf, **kw)
+    q, kv = ops.gemm(x, wf, bf, kv_split=(Cd, L), **kw)
+    assert torch.equal(q, y[:, :Cd])
+    for t in range(2):
+        plain = y[:, (1 + t) * Cd:(2 + t) * Cd].reshape(M // L, L, H, hd).permute(0, 2, 1, 3)
+        assert torch.equal(kv[t], plain)
+    report.append({"test": f"gemm_kv_split[{M},{L}]", "dtype": str(dtype), "identical": True})
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("L,Fr,cfg", [(4096, 2, False), (1024, 3, True), (1000, 2, False)])
+def test_attention_head_major_is_byte_identical(dtype, L, Fr, cfg, report):
+    """hallo_attention on head-major K / V (either or both segments) = the same launch on the fused-buffer views, bit for bit; and
+    both against the fp32 oracle expression."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(L + Fr)
+    H, hd = 8, 40
+    Cd = H * hd
+    nb = 2
+    N = nb * Fr
+    qkv = _rand((N, L, 3 * Cd), dtype, g)
+    bank_kv = _rand((nb, L, 2 * Cd), dtype, g)
+    q = (qkv[:, :, :Cd].float() * ops.q_scale(hd)).to(dtype)
+    k1, v1 = qkv[:, :, Cd:2 * Cd], qkv[:, :, 2 * Cd:]
+    k2, v2 = bank_kv[:, :, :Cd], bank_kv[:, :, Cd:]
+    first = Fr if cfg else 0
+    kw = dict(k2=k2, v2=v2, kv2_batch_div=Fr, kv2_first_batch=first, q_prescaled=True)
+    base = ops.attention(q, k1, v1, H, **kw)
+    k1h, v1h = ops.head_major(k1, v1, H)
+    k2h, v2h = ops.head_major(k2, v2, H)
+    a = ops.attention(q, k1h, v1h, H, kv1_head_major=True, **kw)
+    assert torch.equal(a, base)
+    kw2 = dict(kw, k2=k2h, v2=v2h)
+    a = ops.attention(q, k1h, v1h, H, kv1_head_major=True, kv2_head_major=True, **kw2)
+    assert torch.equal(a, base)
+    a = ops.attention(q, k1, v1, H, kv2_head_major=True, **kw2)
+    assert torch.equal(a, base)
+    a = ops.attention(q, k1h, v1h, H, kv1_head_major=True, q_prescaled=True)
+    assert torch.equal(a, ops.attention(q, k1, v1, H, q_prescaled=True))
+    ref = ops_ref.reference_self_attention(qkv[:, :, :Cd], k1, v1, k2, v2, H, Fr, first)
+    _check(f"attn_head_major[{L},{Fr},{cfg}]", base, ref, dtype, report)
