@@ -261,6 +261,16 @@ static int cmd_attn_time(int argc, char** argv) {
       CK(hipMemcpy2D(qkv, 3 * C * 2, tmp, 3 * C * 2, C * 2, (size_t)c.B * c.L, hipMemcpyDeviceToDevice));
       CK(hipFree(tmp));
       hallo_attn_desc d = attn_desc(qkv, bkv, o, c.B, c.L, H, HD, c.bank, dt);
+      uint16_t *kh = nullptr, *vh = nullptr, *k2h = nullptr, *v2h = nullptr;
+      if (getenv("CBENCH_KV_HM")) {     // head-major K / V ([batch][head][row][40], ABI v9 kv1_hs / kv2_hs): what the pipeline launches since round 6
+        const long n1 = (long)c.B * c.L * C, n2 = (long)(c.bank ? c.bank : 1) * c.L * C;
+        kh = dalloc<uint16_t>(n1); vh = dalloc<uint16_t>(n1); fill(kh, n1, 31 + dt, 1.0f, 0.0f, dt); fill(vh, n1, 37 + dt, 1.0f, 0.0f, dt);
+        d.k1 = kh; d.v1 = vh; d.k1_rs = d.v1_rs = HD; d.k1_bs = d.v1_bs = (long)H * c.L * HD; d.kv1_hs = (long)c.L * HD;
+        if (c.bank) {
+          k2h = dalloc<uint16_t>(n2); v2h = dalloc<uint16_t>(n2); fill(k2h, n2, 41 + dt, 1.0f, 0.0f, dt); fill(v2h, n2, 43 + dt, 1.0f, 0.0f, dt);
+          d.k2 = k2h; d.v2 = v2h; d.k2_rs = d.v2_rs = HD; d.k2_bs = d.v2_bs = (long)H * c.L * HD; d.kv2_hs = (long)c.L * HD;
+        }
+      }
       const double flop = 4.0 * C * c.L * c.B * ((double)c.L * (c.bank ? 2 : 1));
       std::vector<std::vector<float>> t(variants.size());
       for (size_t i = 0; i < variants.size(); ++i) { HK(hallo_set_option("attn40", variants[i])); tm.run([&] { HK(hallo_attention(&d, nullptr)); }, 3); }
@@ -271,10 +281,12 @@ static int cmd_attn_time(int argc, char** argv) {
         }
       for (size_t i = 0; i < variants.size(); ++i) {
         const float us = median(t[i]);
-        printf("attn-time dt=%s case='%s' attn40=%d: %.1f us  %.1f TFLOP/s\n", dt ? "bf16" : "f16", c.name, variants[i], us, flop / us / 1e6);
+        printf("attn-time dt=%s case='%s'%s attn40=%d: %.1f us  %.1f TFLOP/s\n", dt ? "bf16" : "f16", c.name, kh ? " [head-major K/V]" : "", variants[i], us, flop / us / 1e6);
       }
       fflush(stdout);
       CK(hipFree(qkv)); CK(hipFree(bkv)); CK(hipFree(o));
+      if (kh) { CK(hipFree(kh)); CK(hipFree(vh)); }
+      if (k2h) { CK(hipFree(k2h)); CK(hipFree(v2h)); }
     }
   HK(hallo_set_option("attn40", 1));
   return 0;

@@ -47,6 +47,7 @@ def entry(tag, kernel_substr, label, alg_r, alg_w):
     return e
 
 
+# (round 6: the launches are measured with head-major K / V, CBENCH_KV_HM=1 in tools/round_end_gpu.sh -- the layout the pipeline uses)
 qkv_o = F * L * C * es                 # one of q / k / v / o of the clip's frames at L0
 bank = 1 * L * 2 * C * es              # K and V of the reference bank (one frame, shared by the 16 frames)
 res = {

@@ -11,6 +11,7 @@ TAG=${1:-rX}
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+export CBENCH_KV_HM=1     # head-major K / V: the layout the pipeline launches the kernel with since round 6 (tools/cbench attn-time)
 for c in 0 1 3 4; do CBENCH_CASE=$c PMC_GROUPS="fetch write hit" tools/cbench/pmc.sh a40_c$c attn-time 1; done
 python tools/pmc_traffic_cbench.py gpurun_out > gpurun_out/${TAG}_pmc_traffic.json
 timeout 200 tools/cbench/cbench attn-time 1 > gpurun_out/${TAG}_attn_time.txt 2>&1
