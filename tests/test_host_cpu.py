@@ -309,3 +309,23 @@ def test_option_names_export_is_exhaustive(lib=None):
             for m in re.finditer(r'strcmp\(name, "([a-z0-9_]+)"\)\)\s*(?:\|\|[^)]*\)\))?\s*\{\s*if \(value', txt):
                 found.add(m.group(1))
     assert found and found <= set(names), found - set(names)
+
+
+def test_kv_split_query_is_a_host_function():
+    """hallo_gemm_kv_split_ok (ABI v9) answers without a GPU: the head-major K / V epilogue exists for the LayerNorm-fused q|k|v
+    projection of the 320-channel level on the row-stationary kernel only -- K = 320, 640 K / V columns behind the q columns, at
+    least 8192 rows, and not with the row-stationary kernels routed off."""
+    from hallo_amd import lib
+    l = lib.load()
+    assert l.hallo_gemm_kv_split_ok(262144, 960, 320, 320) == 1
+    assert l.hallo_gemm_kv_split_ok(65536, 960, 320, 320) == 1
+    assert l.hallo_gemm_kv_split_ok(4096, 960, 320, 320) == 0          # below the kernel's minimum size
+    assert l.hallo_gemm_kv_split_ok(65536, 1920, 640, 640) == 0        # the 640-channel level: another kernel
+    assert l.hallo_gemm_kv_split_ok(65536, 960, 320, 0) == 0           # 960 columns are not K and V of 8 heads x 40
+    assert l.hallo_gemm_kv_split_ok(65536, 640, 320, 0) == 1           # K | V alone (no q columns)
+    old = l.hallo_get_option(b"gemm_rs")
+    try:
+        assert l.hallo_set_option(b"gemm_rs", 0) == 0
+        assert l.hallo_gemm_kv_split_ok(262144, 960, 320, 320) == 0
+    finally:
+        l.hallo_set_option(b"gemm_rs", old)
