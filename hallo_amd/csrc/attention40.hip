@@ -68,7 +68,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 // of a 32-key block, issued after the 32-row block's MFMAs have consumed them) leaves in the first register the operand of
 // queries 0..15 and in the second that of queries 16..31, key groups (slice, half) = (0,0) (1,0) (0,1) (1,1); the A operand is the
 // same transposing read of V plane B with the 16-lane group choosing (slice, half) instead of (d half, half).
-template <typename T, int EXA, int PRIO, int ABL = 0, bool PV48 = false>
+template <typename T, int EXA, int PRIO, int ABL = 0, bool PV48 = false, int AUX = 0>
 __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   set_segment_v(p.v1_rs);
 
 #define A40_DMA(rs, dst, voff, soff) \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + (dst)), 16, (int)(voff), (int)(soff), 0, 0)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + (dst)), 16, (int)(voff), (int)(soff), 0, AUX)
 
   // Stream cursors (round 3).  The K stream runs three tiles ahead of the tile being consumed, the V stream one: each keeps
   // its OWN position -- descriptor of the current segment, scalar byte offset of the next tile, rows left in the segment --
@@ -514,6 +514,13 @@ static void launch_variant(const AttnArgs& a, dim3 grid, hipStream_t st) {
     case 19: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 32 + 3 + 8 + 16>), grid, dim3(256), 0, st, a); break;
     case 20: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 32 + 64>), grid, dim3(256), 0, st, a); break;
     case 21: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 2 + 128>), grid, dim3(256), 0, st, a); break;
+    // cache-policy bits of the K / V DMA (aux operand of buffer_load ... lds): 1 = sc0, 2 = nt, 16 = sc1
+    case 30: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 1>), grid, dim3(256), 0, st, a); break;
+    case 31: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 2>), grid, dim3(256), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 3>), grid, dim3(256), 0, st, a); break;
+    case 33: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 16>), grid, dim3(256), 0, st, a); break;
+    case 34: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 17>), grid, dim3(256), 0, st, a); break;
+    case 35: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 18>), grid, dim3(256), 0, st, a); break;
 #endif
     default: hipLaunchKernelGGL((attn40_kernel<T, 16, 0>), grid, dim3(256), 0, st, a); break;
   }
