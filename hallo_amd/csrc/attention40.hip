@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
 // barrier) at the 64 x 64-latent level (>= 2048 queries: -0.7...1.2 % per launch, bit-identical outputs in tools/cbench attn-det) and the
 // 64-row form below it (256 x 256-pixel clips, 1024 queries: the 48-row form is 2-5 % slower there); 2.. = fixed forms for A/B:
 // 2 / 3 / 5 = 64-row PV with 0 / 32 / 8 exponentials before the barrier, 4 = raised wave priority around the MFMA clusters,
-// 6 / 7 / 8 = PV48 with 16 / 0 / 32, 9 = the 64-row form of rounds 2-5 (16) at every size
+// 8 = PV48 (32) at every size (6 / 7 = PV48 with 16 / 0: -DHALLO_ABLATIONS builds only), 9 = the 64-row form of rounds 2-5 (16) at every size
 static int g_attn40_variant = 1;
 
 void set_attn40_variant(int v) { g_attn40_variant = v; }
@@ -498,10 +498,10 @@ static void launch_variant(const AttnArgs& a, dim3 grid, hipStream_t st) {
     case 3: hipLaunchKernelGGL((attn40_kernel<T, 32, 0>), grid, dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL((attn40_kernel<T, 16, 1>), grid, dim3(256), 0, st, a); break;
     case 5: hipLaunchKernelGGL((attn40_kernel<T, 8, 0>), grid, dim3(256), 0, st, a); break;
-    case 6: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 0, true>), grid, dim3(256), 0, st, a); break;
-    case 7: hipLaunchKernelGGL((attn40_kernel<T, 0, 0, 0, true>), grid, dim3(256), 0, st, a); break;
     case 8: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true>), grid, dim3(256), 0, st, a); break;
 #ifdef HALLO_ABLATIONS
+    case 6: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 0, true>), grid, dim3(256), 0, st, a); break;
+    case 7: hipLaunchKernelGGL((attn40_kernel<T, 0, 0, 0, true>), grid, dim3(256), 0, st, a); break;
     case 10: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 1>), grid, dim3(256), 0, st, a); break;
     case 11: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 2>), grid, dim3(256), 0, st, a); break;
     case 12: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 3>), grid, dim3(256), 0, st, a); break;
