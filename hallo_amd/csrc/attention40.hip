@@ -68,7 +68,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 // of a 32-key block, issued after the 32-row block's MFMAs have consumed them) leaves in the first register the operand of
 // queries 0..15 and in the second that of queries 16..31, key groups (slice, half) = (0,0) (1,0) (0,1) (1,1); the A operand is the
 // same transposing read of V plane B with the 16-lane group choosing (slice, half) instead of (d half, half).
-template <typename T, int EXA, int PRIO, int ABL = 0, bool PV48 = false, int AUX = 0>
+template <typename T, int EXA, int PRIO, int ABL = 0, bool PV48 = false, int AUX = 0, bool KPRE = false>
 __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
@@ -282,6 +282,20 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   auto tile_step = [&](auto more_c, auto par_c, int it, f32x16* s_cur, f32x16* s_nxt) {
     constexpr bool MORE = decltype(more_c)::value;      // a tile it+1 exists
     constexpr int PAR = decltype(par_c)::value;         // it & 1
+    // KPRE (round 6, default with PV48): the six K fragments of tile it+1 are requested before the softmax statistics of tile it instead of
+    // next to their MFMAs (hipcc's own placement waits for the second block's three reads at the barrier): -0.9 % per launch, same results
+    V8 kpre[NT][3];
+    if (KPRE && MORE) {
+      constexpr int ST = (1 - PAR) * A40_K_TILE;
+      typedef const __attribute__((address_space(3))) V8* ldsv8;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        kpre[t][0] = *(ldsv8)(kb01 + ST + t * 32 * 80);
+        kpre[t][1] = *(ldsv8)(kb01 + ST + t * 32 * 80 + 32);
+        kpre[t][2] = *(ldsv8)(kb2 + ST + t * 32 * 80);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     if (__builtin_expect(cons_left < KVB, 0)) {
       asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch
@@ -337,7 +351,14 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
 
     // ---- A: QK^T of tile it+1 | first exponentials of tile it ----
     if (PRIO) __builtin_amdgcn_s_setprio(1);
-    if (MORE) qk(std::integral_constant<int, 1 - PAR>{}, s_nxt);
+    if (KPRE && MORE) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        s_nxt[t] = Vec<T>::mfma32(kpre[t][0], qf[0], zero16);
+        s_nxt[t] = Vec<T>::mfma32(kpre[t][1], qf[1], s_nxt[t]);
+        s_nxt[t] = Vec<T>::mfma32(kpre[t][2], qf[2], s_nxt[t]);
+      }
+    } else if (MORE) qk(std::integral_constant<int, 1 - PAR>{}, s_nxt);
     if (PRIO) __builtin_amdgcn_s_setprio(0);
     V8 pf[NT][2];
     auto pexp = [&](float x) { return (ABL & 4) ? x * 0.001f : __builtin_amdgcn_exp2f(x); };
@@ -480,7 +501,8 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
 
 // hallo_set_option("attn40", v): 0 = attention.hip; 1 (default) = this kernel, the 48-row PV form (PV48, all exponentials before the
 // barrier) at the 64 x 64-latent level (>= 2048 queries: -0.7...1.2 % per launch, bit-identical outputs in tools/cbench attn-det) and the
-// 64-row form below it (256 x 256-pixel clips, 1024 queries: the 48-row form is 2-5 % slower there); 2.. = fixed forms for A/B:
+// 64-row form below it (256 x 256-pixel clips, 1024 queries: the 48-row form is 2-5 % slower there); the PV48 launches also request
+// their K fragments early (KPRE: another -0.9 %, profiles/r6_attn40_pv48.txt); 2.. = fixed forms for A/B:
 // 2 / 3 / 5 = 64-row PV with 0 / 32 / 8 exponentials before the barrier, 4 = raised wave priority around the MFMA clusters,
 // 8 = PV48 (32) at every size (6 / 7 = PV48 with 16 / 0: -DHALLO_ABLATIONS builds only), 9 = the 64-row form of rounds 2-5 (16) at every size
 static int g_attn40_variant = 1;
@@ -491,7 +513,7 @@ template <typename T>
 static void launch_variant(const AttnArgs& a, dim3 grid, hipStream_t st) {
   switch (g_attn40_variant) {
     case 1:
-      if (a.nqb >= 16) hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true>), grid, dim3(256), 0, st, a);
+      if (a.nqb >= 16) hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 0, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((attn40_kernel<T, 16, 0>), grid, dim3(256), 0, st, a);
       break;
     case 2: hipLaunchKernelGGL((attn40_kernel<T, 0, 0>), grid, dim3(256), 0, st, a); break;
@@ -521,6 +543,8 @@ static void launch_variant(const AttnArgs& a, dim3 grid, hipStream_t st) {
     case 33: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 16>), grid, dim3(256), 0, st, a); break;
     case 34: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 17>), grid, dim3(256), 0, st, a); break;
     case 35: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 18>), grid, dim3(256), 0, st, a); break;
+    case 36: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 0, true>), grid, dim3(256), 0, st, a); break;
+    case 37: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 0, true, 0, true>), grid, dim3(256), 0, st, a); break;
 #endif
     default: hipLaunchKernelGGL((attn40_kernel<T, 16, 0>), grid, dim3(256), 0, st, a); break;
   }
