@@ -113,9 +113,8 @@ class OpProfiler:
             if which == 3:
                 return "tok_attn_kernel<%s,%d>" % (dt, hd)    # csrc/attention.hip: K/V of <= 32 rows, query tiles through LDS
             if which == 2:
-                # csrc/attention40.hip (LDS-DMA K/V, transposing V reads): <T, EXA, PRIO, ABL, PV48, AUX, KPRE>; the default rule launches the
-                # 48-row PV form from 2048 queries (the 64 x 64-latent level) and the 64-row form below
-                return "attn40_kernel<%s,32,0,0,true,0,true>" % dt if a[0].shape[1] >= 1921 else "attn40_kernel<%s,16,0,0,false,0,false>" % dt
+                # csrc/attention40.hip (LDS-DMA K/V, transposing V reads): <T, EXA, PRIO, ABL, PV48, AUX, KPRE>; a product build has the one form
+                return "attn40_kernel<%s,32,0,0,true,0,true>" % dt
             return "attn_kernel<%s,%d,%s>" % (dt, hd, "true" if k.get("q_prescaled") else "false")
         return name
 

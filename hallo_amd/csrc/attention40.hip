@@ -253,6 +253,20 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
       sc[t] = Vec<T>::mfma32(k2, qf[2], sc[t]);
     }
   };
+  // the six K fragments of a stage, without their MFMAs (KPRE)
+  auto kload = [&](auto stg_c, auto on_c, auto* kf) {
+    if constexpr (KPRE && decltype(on_c)::value) {
+      constexpr int ST = decltype(stg_c)::value * A40_K_TILE;
+      typedef const __attribute__((address_space(3))) V8* ldsv8;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        kf[t][0] = *(ldsv8)(kb01 + ST + t * 32 * 80);
+        kf[t][1] = *(ldsv8)(kb01 + ST + t * 32 * 80 + 32);
+        kf[t][2] = *(ldsv8)(kb2 + ST + t * 32 * 80);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   auto tr4 = [&](const lds_u8* ptr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
   };
@@ -284,18 +298,8 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
     constexpr int PAR = decltype(par_c)::value;         // it & 1
     // KPRE (round 6, default with PV48): the six K fragments of tile it+1 are requested before the softmax statistics of tile it instead of
     // next to their MFMAs (hipcc's own placement waits for the second block's three reads at the barrier): -0.9 % per launch, same results
-    V8 kpre[NT][3];
-    if (KPRE && MORE) {
-      constexpr int ST = (1 - PAR) * A40_K_TILE;
-      typedef const __attribute__((address_space(3))) V8* ldsv8;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        kpre[t][0] = *(ldsv8)(kb01 + ST + t * 32 * 80);
-        kpre[t][1] = *(ldsv8)(kb01 + ST + t * 32 * 80 + 32);
-        kpre[t][2] = *(ldsv8)(kb2 + ST + t * 32 * 80);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    typename std::conditional<KPRE, V8, char>::type kpre[NT][3];      // (no V8 object at all in the forms without KPRE: a dead V8 array there cost them 4 spilled VGPRs)
+    kload(std::integral_constant<int, 1 - PAR>{}, more_c, kpre);
 
     if (__builtin_expect(cons_left < KVB, 0)) {
       asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch
@@ -351,7 +355,8 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
 
     // ---- A: QK^T of tile it+1 | first exponentials of tile it ----
     if (PRIO) __builtin_amdgcn_s_setprio(1);
-    if (KPRE && MORE) {
+    if constexpr (KPRE && MORE) {
+      // (the two blocks' chains interleaved -- t inner, k16 step outer -- is 1 % SLOWER: profiles/r6_attn40_pv48.txt)
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         s_nxt[t] = Vec<T>::mfma32(kpre[t][0], qf[0], zero16);
@@ -499,12 +504,13 @@ __global__ __launch_bounds__(256, 3) void attn40_kernel(const AttnArgs p) {
   }
 }
 
-// hallo_set_option("attn40", v): 0 = attention.hip; 1 (default) = this kernel, the 48-row PV form (PV48, all exponentials before the
-// barrier) at the 64 x 64-latent level (>= 2048 queries: -0.7...1.2 % per launch, bit-identical outputs in tools/cbench attn-det) and the
-// 64-row form below it (256 x 256-pixel clips, 1024 queries: the 48-row form is 2-5 % slower there); the PV48 launches also request
-// their K fragments early (KPRE: another -0.9 %, profiles/r6_attn40_pv48.txt); 2.. = fixed forms for A/B:
-// 2 / 3 / 5 = 64-row PV with 0 / 32 / 8 exponentials before the barrier, 4 = raised wave priority around the MFMA clusters,
-// 8 = PV48 (32) at every size (6 / 7 = PV48 with 16 / 0: -DHALLO_ABLATIONS builds only), 9 = the 64-row form of rounds 2-5 (16) at every size
+// hallo_set_option("attn40", v): 0 = attention.hip; 1 (default, and any other value in a product build) = this kernel in its round-6 form:
+// 48-row PV (PV48), all 32 exponentials before the barrier, K fragments of the next tile requested ahead of the softmax statistics (KPRE).
+// -DHALLO_ABLATIONS builds keep the earlier forms for A/B (tools/cbench attn-time / attn-det): 2 / 3 / 5 / 9 = 64-row PV with 0 / 32 / 8 / 16
+// exponentials before the barrier (9 = the kernel of rounds 2-5), 4 = raised wave priority around the MFMA clusters, 6 / 7 / 8 = PV48 without
+// KPRE (16 / 0 / 32), 10..21 timing ablations, 30..35 cache-policy bits of the K / V DMA, 36 / 37 = PV48 + KPRE (32 / 16).  (In the shared source
+// the 64-row forms cost 4 spilled VGPRs since KPRE exists -- one more reason they are not in the product build; at 1024 queries the
+// default form is now the faster one too: 34.7 vs 35.5 us.)
 static int g_attn40_variant = 1;
 
 void set_attn40_variant(int v) { g_attn40_variant = v; }
@@ -512,16 +518,13 @@ void set_attn40_variant(int v) { g_attn40_variant = v; }
 template <typename T>
 static void launch_variant(const AttnArgs& a, dim3 grid, hipStream_t st) {
   switch (g_attn40_variant) {
-    case 1:
-      if (a.nqb >= 16) hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 0, true>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((attn40_kernel<T, 16, 0>), grid, dim3(256), 0, st, a);
-      break;
+#ifdef HALLO_ABLATIONS
     case 2: hipLaunchKernelGGL((attn40_kernel<T, 0, 0>), grid, dim3(256), 0, st, a); break;
     case 3: hipLaunchKernelGGL((attn40_kernel<T, 32, 0>), grid, dim3(256), 0, st, a); break;
     case 4: hipLaunchKernelGGL((attn40_kernel<T, 16, 1>), grid, dim3(256), 0, st, a); break;
     case 5: hipLaunchKernelGGL((attn40_kernel<T, 8, 0>), grid, dim3(256), 0, st, a); break;
     case 8: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true>), grid, dim3(256), 0, st, a); break;
-#ifdef HALLO_ABLATIONS
+    case 9: hipLaunchKernelGGL((attn40_kernel<T, 16, 0>), grid, dim3(256), 0, st, a); break;
     case 6: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 0, true>), grid, dim3(256), 0, st, a); break;
     case 7: hipLaunchKernelGGL((attn40_kernel<T, 0, 0, 0, true>), grid, dim3(256), 0, st, a); break;
     case 10: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 1>), grid, dim3(256), 0, st, a); break;
@@ -546,7 +549,7 @@ static void launch_variant(const AttnArgs& a, dim3 grid, hipStream_t st) {
     case 36: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 0, true>), grid, dim3(256), 0, st, a); break;
     case 37: hipLaunchKernelGGL((attn40_kernel<T, 16, 0, 0, true, 0, true>), grid, dim3(256), 0, st, a); break;
 #endif
-    default: hipLaunchKernelGGL((attn40_kernel<T, 16, 0>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((attn40_kernel<T, 32, 0, 0, true, 0, true>), grid, dim3(256), 0, st, a); break;
   }
 }
 
