@@ -260,7 +260,7 @@ def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, 
     if kv_split is not None:
         col0, L = kv_split
         assert out is None and not geglu and not out_f32 and N - col0 == 640 and M % L == 0 and lead_cols <= col0
-        out = torch.empty((M, col0), device=a.device, dtype=a.dtype)
+        out = torch.empty((M, max(col0, 8)), device=a.device, dtype=a.dtype)     # (col0 = 0, K | V alone: the library still wants a valid C)
         kv = torch.empty((2, M // L, 8, L, 40), device=a.device, dtype=a.dtype)
     elif out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
@@ -315,7 +315,7 @@ def gemm(a, w, bias=None, *, out=None, residual=None, rowscale=None, alpha=1.0, 
     d.workspace, d.workspace_bytes, d.workspace_zeroed = ws.data_ptr(), SPLITK_WS_BYTES, WS_ZEROED
     _l.check(_l.load().hallo_gemm(C.byref(d), _stream()), "hallo_gemm")
     if kv is not None:
-        return out, kv
+        return out[:, :kv_split[0]], kv
     return (out, parts) if row_parts else out
 
 
