@@ -611,3 +611,23 @@ def test_attention_head_major_is_byte_identical(dtype, L, Fr, cfg, report):
     assert torch.equal(a, ops.attention(q, k1, v1, H, q_prescaled=True))
     ref = ops_ref.reference_self_attention(qkv[:, :, :Cd], k1, v1, k2, v2, H, Fr, first)
     _check(f"attn_head_major[{L},{Fr},{cfg}]", base, ref, dtype, report)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_hd40_output_row_scale(dtype, report):
+    """The fp32 output row scale through the hd-40 LDS-DMA kernel (K / V longer than the token kernel takes): every 16-row block of
+    its 48-row PV form fetches the scale of ITS query from another lane."""
+    from hallo_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(5)
+    B, H, hd, Lq, Lkv = 2, 8, 40, 300, 96
+    Cd = H * hd
+    q = _rand((B, Lq, Cd), dtype, g)
+    k = _rand((B, Lkv, Cd), dtype, g)
+    v = _rand((B, Lkv, Cd), dtype, g)
+    rs = (0.25 + torch.rand((2, B * Lq), generator=g)).to(_dev())
+    qs = (q.float() * ops.q_scale(hd)).to(dtype)
+    out = ops.attention(qs, k, v, H, q_prescaled=True, rowscale=rs, rowscale_head_div=4)
+    assert ops.get_option("last_attn_kernel") == 2
+    ref = ops_ref.sdpa(q, k, v, H).float().view(B * Lq, 2, 4 * hd) * rs.t()[:, :, None]
+    _check("attn40_rowscale", out, ref.view(B, Lq, Cd), dtype, report)
